@@ -1,0 +1,159 @@
+/* mips_hip.h -- C ABI of the MI355X-native MIPS (maximum inner product search) backend.
+ *
+ * Drop-in boundary for ONE path of florianbaud/retrieval-augmented-mds ("sotasum"):
+ * the exact top-k inner-product search that sotasum/mips.py performs through a CPU
+ * FAISS IndexFlat.  The reference is pure Python and has no FFI of its own; the seam it
+ * exposes is the Python duck type `faiss_index.search(x, k) -> (D, I)`
+ * (sotasum/mips.py:383-386).  The entry points below are what a ctypes binding for that
+ * seam binds (INTEGRATION.md shows the stub); each one cites the reference interface it
+ * stands in for.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *   - every function returns 0 on success or a negative MIPS_E_* code; the message for
+ *     the calling thread is available from mips_last_error().  No C++ exception escapes.
+ *   - the caller owns every input/output buffer; the library owns the index storage in
+ *     HBM and its scratch.  Work is enqueued on the HIP stream passed in (NULL = the
+ *     default stream); there is no hidden device-wide synchronisation.  Calls that take
+ *     HOST output buffers synchronise that stream before returning.
+ *   - one index lives on one GPU.  Concurrent calls on one index must be serialised by
+ *     the caller (the Python wrapper holds a lock).
+ *   - ties: the lowest document index wins (the reference leaves ties undefined).
+ *   - padding (FAISS IndexFlat convention): when k > ntotal the tail of every row is
+ *     idx = -1, score = -inf (inner product) or +inf (L2).
+ *
+ * Score definition (see DESIGN.md "Canonical score"): candidates are found with bf16 MFMA
+ * products accumulated in fp32; the final k results are re-scored exactly,
+ *     score = (float) sum_{j=0..d-1, sequential, fp64} q[j] * x[j]
+ * on the values as stored in the index (bf16-rounded), and ordered by (score desc, idx asc).
+ */
+#ifndef MIPS_HIP_H
+#define MIPS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIPS_ABI_VERSION 1
+
+/* element types of caller buffers / of the index storage */
+#define MIPS_DTYPE_F32 0
+#define MIPS_DTYPE_BF16 1
+#define MIPS_DTYPE_FP8_E4M3 2 /* reserved: index storage dtype of BASELINE config 5 */
+
+/* faiss.METRIC_INNER_PRODUCT / faiss.METRIC_L2 as used by mips.py:306,316,369,371 */
+#define MIPS_METRIC_IP 0
+#define MIPS_METRIC_L2 1
+
+/* mips_search flags */
+#define MIPS_Q_DEVICE 1   /* queries pointer is device memory */
+#define MIPS_OUT_DEVICE 2 /* out_scores / out_idx are device memory */
+
+/* synthetic data kinds (same functions as oracle/synth.py) */
+#define MIPS_SYNTH_LATTICE 0
+#define MIPS_SYNTH_GAUSS 1
+#define MIPS_SYNTH_LATTICE_FP8 2
+
+#define MIPS_OK 0
+#define MIPS_E_INVALID -1     /* bad argument */
+#define MIPS_E_HIP -2         /* a HIP runtime call failed */
+#define MIPS_E_UNSUPPORTED -3 /* valid request this build does not implement */
+#define MIPS_E_NOMEM -4       /* device allocation failed */
+
+#define MIPS_MAX_K 29 /* largest k one mips_search call accepts */
+
+typedef struct mips_index mips_index_t;
+
+/* ABI version of the loaded library (compare with MIPS_ABI_VERSION). */
+int mips_abi_version(void);
+
+/* Message of the last failing call on this thread ("" if none). */
+const char* mips_last_error(void);
+
+/* Create an empty index of dimension d on GPU `device`.
+ * Replaces: datasets.Dataset.add_faiss_index(string_factory="Flat", metric_type=...) ->
+ * faiss.IndexFlat(d, metric), sotasum/mips.py:333-340 and retriever_lightning.py:395-404.
+ * doc_dtype is the storage type in HBM (MIPS_DTYPE_BF16). */
+int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, int metric);
+
+/* Free the index and its scratch.  Replaces Dataset.drop_index (mips.py:537). */
+int mips_index_destroy(mips_index_t* index);
+
+/* Pre-size the HBM storage for n rows (optional; add grows geometrically otherwise). */
+int mips_index_reserve(mips_index_t* index, int64_t n);
+
+/* Append n rows of dimension d.  rows: [n, d] row-major of src_dtype (F32 or BF16), in
+ * host (src_is_device = 0) or device memory.  F32 input is rounded to bf16 (RNE) on the
+ * device.  Replaces faiss Index.add as driven by HF datasets in batches of 1000 rows
+ * (mips.py:333-340). */
+int mips_index_add(mips_index_t* index, const void* rows, int64_t n, int src_dtype,
+                   int src_is_device, void* hip_stream);
+
+/* Drop all rows, keep the allocation.  Replaces faiss Index.reset. */
+int mips_index_reset(mips_index_t* index);
+
+/* faiss Index.ntotal / Index.d / metric_type */
+int64_t mips_index_ntotal(const mips_index_t* index);
+int64_t mips_index_dim(const mips_index_t* index);
+int mips_index_metric(const mips_index_t* index);
+
+/* phi = max_i |x_i|^2 over the stored rows (fp64), the constant of the MIPS->L2 reduction
+ * (mips.py:55-56, 316-324).  Synchronises the stream. */
+int mips_index_phi(mips_index_t* index, double* out_phi, void* hip_stream);
+
+/* Copy stored rows [row0, row0+n) as bf16 bit patterns (uint16, [n, d]) to HOST memory.
+ * Used by save() (replaces Dataset.save_faiss_index, mips.py:536) and by tests. */
+int mips_index_read_rows(mips_index_t* index, int64_t row0, int64_t n, void* out_host_u16,
+                         void* hip_stream);
+
+/* Append n rows generated on the device by the counter-based generator
+ * value(seed, row, col) with row = row0 .. row0+n-1 (global row numbers, so row shards of
+ * one logical index are generated independently).  kind: MIPS_SYNTH_*. */
+int mips_index_add_synthetic(mips_index_t* index, int64_t n, int64_t row0, uint64_t seed,
+                             int kind, void* hip_stream);
+
+/* Fill a DEVICE buffer [n, d] of dtype (F32 or BF16) with generator values. */
+int mips_synth_fill(void* out_device, int64_t n, int64_t d, int64_t row0, uint64_t seed,
+                    int kind, int dtype, int device, void* hip_stream);
+
+/* Exact top-k search.  Replaces faiss_index.search(queries, k) at sotasum/mips.py:383-386
+ * (and get_nearest_examples_batch at retriever_lightning.py:317-321).
+ *   q          [nq, d] row-major, q_dtype F32 or BF16, host or device (MIPS_Q_DEVICE)
+ *   out_scores [nq, k] float32, out_idx [nq, k] int64, host or device (MIPS_OUT_DEVICE)
+ *   idx_offset added to every returned index (row offset of this shard)
+ * Inner product: scores descending.  L2: squared distances on the phi-augmented vectors
+ * (|q|^2 + phi - 2 q.x, mips.py:59-70,316-331), ascending. */
+int mips_search(mips_index_t* index, const void* q, int q_dtype, int64_t nq, int k,
+                float* out_scores, int64_t* out_idx, int64_t idx_offset, int flags,
+                void* hip_stream);
+
+/* Merge `parts` per-shard top-k lists into the global top-k (the step after the RCCL
+ * all-gather; nothing in the reference corresponds, its index is replicated per rank,
+ * lightning_model.py:180).  cand_s / cand_i: DEVICE [nq, parts*k] (shard-major inside a
+ * row), out_s / out_i: DEVICE [nq, k].  Order (score desc | asc for L2, idx asc), idx < 0
+ * last. */
+int mips_merge_topk(const float* cand_s, const int64_t* cand_i, int64_t nq, int parts, int k,
+                    int metric, float* out_s, int64_t* out_i, int device, void* hip_stream);
+
+/* In-place row L2 normalisation of a DEVICE float32 matrix [n, d].  Replaces
+ * faiss.normalize_L2 behind Mips.l2_normalization (sotasum/mips.py:521-525), used for documents
+ * at build time (mips.py:306-314, 358-361) and for queries (mips.py:369-370).  Rows of norm 0 are
+ * left unchanged (faiss fvec_renorm_L2). */
+int mips_l2_normalize(float* x_device, int64_t n, int64_t d, int device, void* hip_stream);
+
+/* max_i |x_i|^2 of a DEVICE float32 matrix, written to *out_host (stream synchronised).  Its
+ * square root is the reference's max_norm (mips.py:298-304, 347-349). */
+int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out_host, int device,
+                        void* hip_stream);
+
+/* Timing hook used by bench.py: duration in milliseconds of the fused scan kernel of the
+ * most recent mips_search on this index, measured with HIP events on the search stream
+ * (valid after that stream was synchronised; < 0 if unavailable). */
+int mips_last_scan_ms(mips_index_t* index, float* out_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIPS_HIP_H */

@@ -1,0 +1,23 @@
+"""MI355X-native dense retrieval (exact MIPS) backend for sotasum's `Mips` path.
+
+    import retrieval_augmented_mds_amd as ram          # alias module at the repo root
+    index = ram.MipsIndex(768); index.add(x); D, I = index.search(q, 5)
+    mips = ram.Mips(ram.MipsArgs(mips_topk=5), data={"mips_column": texts, "aid": aids})
+
+Everything numeric runs in libmips_hip.so (hand-written HIP for gfx950, csrc/); there is no CPU
+fallback.  See DESIGN.md and include/mips_hip.h.
+"""
+from . import _lib
+from ._lib import (DTYPE_BF16, DTYPE_F32, MAX_K, METRIC_IP, METRIC_L2, SYNTH_GAUSS, SYNTH_LATTICE,
+                   SYNTH_LATTICE_FP8, build)
+from .index import MipsIndex, l2_normalize_, merge_topk, rows_max_sumsq, synth_fill
+from .mips import (KnowledgeBase, Mips, MipsArgs, MipsModelOutput, augment_xb, augment_xq, get_phi,
+                   inner_product, retriever_metrics)
+from .sharded import ShardedMipsIndex, pack_topk, shard_bounds, unpack_gathered
+
+__all__ = [
+    "MipsIndex", "ShardedMipsIndex", "Mips", "MipsArgs", "MipsModelOutput", "KnowledgeBase",
+    "get_phi", "augment_xb", "augment_xq", "inner_product", "retriever_metrics",
+    "l2_normalize_", "rows_max_sumsq", "merge_topk", "synth_fill", "shard_bounds", "pack_topk",
+    "unpack_gathered", "build", "METRIC_IP", "METRIC_L2", "MAX_K",
+]

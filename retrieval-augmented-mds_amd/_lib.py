@@ -1,0 +1,143 @@
+"""ctypes binding of the C ABI declared in include/mips_hip.h (libmips_hip.so, hipcc, gfx950).
+
+There is NO CPU fallback: if the library cannot be built or loaded, or no GPU is visible when a
+device call is made, the product raises.  (The CPU oracle under oracle/ is test infrastructure and
+is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libmips_hip.so")
+HEADER = os.path.join(_ROOT, "include", "mips_hip.h")
+ABI_VERSION = 1
+
+# constants of include/mips_hip.h
+DTYPE_F32, DTYPE_BF16, DTYPE_FP8_E4M3 = 0, 1, 2
+METRIC_IP, METRIC_L2 = 0, 1
+Q_DEVICE, OUT_DEVICE = 1, 2
+SYNTH_LATTICE, SYNTH_GAUSS, SYNTH_LATTICE_FP8 = 0, 1, 2
+MAX_K = 29
+
+_lock = threading.Lock()
+_lib = None
+
+
+def _sources():
+    out = [HEADER]
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".hpp", ".h")):
+            out.append(os.path.join(CSRC, f))
+    return out
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(s) > t for s in _sources())
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 csrc/mips_hip.hip -> lib/libmips_hip.so (in-tree)."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libmips_hip.so (no CPU fallback exists)")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    tmp = LIB_PATH + f".tmp{os.getpid()}"
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+           "-o", tmp, os.path.join(CSRC, "mips_hip.hip")]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+def _bind(lib):
+    c = ctypes
+    vp, i64, i32, u64 = c.c_void_p, c.c_int64, c.c_int, c.c_uint64
+    sig = {
+        "mips_abi_version": (i32, []),
+        "mips_last_error": (c.c_char_p, []),
+        "mips_index_create": (i32, [c.POINTER(vp), i32, i64, i32, i32]),
+        "mips_index_destroy": (i32, [vp]),
+        "mips_index_reserve": (i32, [vp, i64]),
+        "mips_index_add": (i32, [vp, vp, i64, i32, i32, vp]),
+        "mips_index_reset": (i32, [vp]),
+        "mips_index_ntotal": (i64, [vp]),
+        "mips_index_dim": (i64, [vp]),
+        "mips_index_metric": (i32, [vp]),
+        "mips_index_phi": (i32, [vp, c.POINTER(c.c_double), vp]),
+        "mips_index_read_rows": (i32, [vp, i64, i64, vp, vp]),
+        "mips_index_add_synthetic": (i32, [vp, i64, i64, u64, i32, vp]),
+        "mips_synth_fill": (i32, [vp, i64, i64, i64, u64, i32, i32, i32, vp]),
+        "mips_search": (i32, [vp, vp, i32, i64, i32, vp, vp, i64, i32, vp]),
+        "mips_merge_topk": (i32, [vp, vp, i64, i32, i32, i32, vp, vp, i32, vp]),
+        "mips_l2_normalize": (i32, [vp, i64, i64, i32, vp]),
+        "mips_rows_max_sumsq": (i32, [vp, i64, i64, c.POINTER(c.c_double), i32, vp]),
+        "mips_last_scan_ms": (i32, [vp, c.POINTER(c.c_float)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return sig
+
+
+EXPORTS = (
+    "mips_abi_version", "mips_last_error", "mips_index_create", "mips_index_destroy",
+    "mips_index_reserve", "mips_index_add", "mips_index_reset", "mips_index_ntotal",
+    "mips_index_dim", "mips_index_metric", "mips_index_phi", "mips_index_read_rows",
+    "mips_index_add_synthetic", "mips_synth_fill", "mips_search", "mips_merge_topk",
+    "mips_l2_normalize", "mips_rows_max_sumsq", "mips_last_scan_ms",
+)
+
+
+def load():
+    """Load (building first if needed) libmips_hip.so.  torch is imported first on purpose: its
+    bundled libamdhip64 has the same SONAME as /opt/rocm's, so the dynamic loader binds our
+    library to the HIP runtime torch already brought in -- one runtime per process, and torch
+    device pointers are valid in our calls."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        import torch  # noqa: F401  (must precede dlopen, see docstring)
+
+        path = build()
+        lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        _bind(lib)
+        ver = lib.mips_abi_version()
+        if ver != ABI_VERSION:
+            raise RuntimeError(f"libmips_hip.so ABI {ver} != expected {ABI_VERSION}; rebuild")
+        _lib = lib
+        return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().mips_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what or 'libmips_hip'} failed (code {rc}): {msg}")
+
+
+def require_gpu(device: int | None = None) -> int:
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "retrieval-augmented-mds_amd: no AMD GPU visible; this backend has no CPU path "
+            "(the reference's CPU FAISS search is what it replaces)")
+    return torch.cuda.current_device() if device is None else int(device)

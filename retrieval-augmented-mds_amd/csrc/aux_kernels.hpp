@@ -1,0 +1,341 @@
+// Kernels either side of the fused scan: dtype conversion into the index layout, the synthetic
+// generators of SURVEY.md 8d, the split merge + exact re-score, and the cross-shard merge.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "scan_kernel.hpp"
+
+namespace mips {
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0; // NaN stays NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+
+// ------------------------------------------------------------------ conversion into [rows][ld] bf16
+// one thread per 8 output elements; columns >= d are written as zero.
+template <typename SRC>
+__global__ void convert_rows_kernel(const SRC* __restrict__ src, int64_t n, int d, uint16_t* dst, int ld) {
+    const int chunks = ld / 8;
+    const int64_t total = n * chunks;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / chunks;
+        const int c0 = (int)(t % chunks) * 8;
+        uint16_t v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            if (c < d) {
+                if constexpr (sizeof(SRC) == 4)
+                    v[e] = f32_to_bf16_rne(((const float*)src)[row * d + c]);
+                else
+                    v[e] = ((const uint16_t*)src)[row * d + c];
+            } else {
+                v[e] = 0;
+            }
+        }
+        u32x4 o;
+        o[0] = v[0] | ((uint32_t)v[1] << 16);
+        o[1] = v[2] | ((uint32_t)v[3] << 16);
+        o[2] = v[4] | ((uint32_t)v[5] << 16);
+        o[3] = v[6] | ((uint32_t)v[7] << 16);
+        *reinterpret_cast<u32x4*>(dst + row * ld + c0) = o;
+    }
+}
+
+__global__ void zero_rows_kernel(uint16_t* dst, int64_t nrows, int ld) {
+    const int64_t total = nrows * (ld / 8);
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        u32x4 z = {0u, 0u, 0u, 0u};
+        reinterpret_cast<u32x4*>(dst)[t] = z;
+    }
+}
+
+// ------------------------------------------------------------------ synthetic generators
+// Bit-identical to oracle/synth.py (a GPU test checks it).
+__host__ __device__ __forceinline__ uint64_t synth_mix(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ uint64_t synth_row_key(uint64_t seed, uint64_t row) {
+    return synth_mix(seed ^ (row * 0xD6E8FEB86659FD93ull));
+}
+__device__ __forceinline__ float synth_value(uint64_t key, uint64_t col, int kind) {
+    if (kind == 1) { // GAUSS: centred sum of eight 16-bit uniforms, scaled, rounded to bf16
+        const uint64_t h1 = synth_mix(key + 2 * col), h2 = synth_mix(key + 2 * col + 1);
+        int s = 0;
+#pragma unroll
+        for (int sh = 0; sh < 64; sh += 16) s += (int)((h1 >> sh) & 0xffff) + (int)((h2 >> sh) & 0xffff);
+        s -= 4 * 65535;
+        const float x = (float)s * (float)(1.0 / (65536.0 * 0.816496580927726));
+        return bf16_bits_to_f32(f32_to_bf16_rne(x));
+    }
+    const uint64_t hsh = synth_mix(key + col) >> 40;
+    if (kind == 2) return (float)((int)(hsh % 17) - 8) / 8.0f; // LATTICE_FP8
+    return (float)((int)(hsh % 255) - 127) / 64.0f;            // LATTICE
+}
+
+// out: bf16 [n][ld] (as_f32 == 0) or f32 [n][ld] (as_f32 == 1); columns >= d are zero
+__global__ void synth_fill_kernel(void* out, int64_t n, int d, int ld, int64_t row0, uint64_t seed, int kind,
+                                  int as_f32) {
+    const int chunks = ld / 8;
+    const int64_t total = n * chunks;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / chunks;
+        const int c0 = (int)(t % chunks) * 8;
+        const uint64_t key = synth_row_key(seed, (uint64_t)(row0 + row));
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (c0 + e < d) ? synth_value(key, (uint64_t)(c0 + e), kind) : 0.f;
+        if (as_f32) {
+            float* o = (float*)out + row * ld + c0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = v[e];
+        } else {
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[e] = f32_to_bf16_rne(v[2 * e]) | ((uint32_t)f32_to_bf16_rne(v[2 * e + 1]) << 16);
+            *reinterpret_cast<u32x4*>((uint16_t*)out + row * ld + c0) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ phi = max row |x|^2 (fp64, sequential)
+__global__ void row_sumsq_max_kernel(const uint16_t* rows, int64_t n, int ld, unsigned long long* out_bits) {
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint16_t* x = rows + r * ld;
+    double acc = 0.0;
+    for (int c = 0; c < ld; c += 8) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double a = (double)bf16_bits_to_f32(v[e] & 0xffffu);
+            const double b = (double)bf16_bits_to_f32(v[e] >> 16);
+            acc += a * a;
+            acc += b * b;
+        }
+    }
+    // non-negative doubles order like their bit patterns
+    atomicMax(out_bits, (unsigned long long)__double_as_longlong(acc));
+}
+
+// ------------------------------------------------------------------ row L2 normalisation (fp32, in place)
+// Replaces faiss.normalize_L2 as used by Mips.l2_normalization (sotasum/mips.py:521-525; faiss
+// fvec_renorm_L2: nr = sum x^2 in fp32, x *= 1/sqrtf(nr) when nr > 0).  One wave per row.
+__global__ __launch_bounds__(256) void l2_normalize_kernel(float* x, int64_t n, int d) {
+    const int64_t row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    float* r = x + row * d;
+    float nr = 0.f;
+    for (int c = lane; c < d; c += 64) nr += r[c] * r[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nr += __shfl_xor(nr, off);
+    if (nr > 0.f) {
+        const float inv = 1.0f / sqrtf(nr);
+        for (int c = lane; c < d; c += 64) r[c] *= inv;
+    }
+}
+
+// max over rows of |x|^2 for fp32 rows (fp64 accumulation); max_norm of mips.py:298-304 is its sqrt
+__global__ __launch_bounds__(256) void f32_rows_max_sumsq_kernel(const float* x, int64_t n, int d,
+                                                                 unsigned long long* out_bits) {
+    const int64_t row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const float* r = x + row * d;
+    double acc = 0.0;
+    for (int c = lane; c < d; c += 64) acc += (double)r[c] * (double)r[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(acc));
+}
+
+// ------------------------------------------------------------------ split merge + exact re-score
+__device__ __forceinline__ bool ranks_before(float s1, int i1, float s2, int i2) {
+    return s1 > s2 || (s1 == s2 && i1 < i2);
+}
+
+template <int KL>
+__device__ __forceinline__ void list_insert_full(float (&ls)[KL], int (&li)[KL], float s, int id) {
+    ls[KL - 1] = s;
+    li[KL - 1] = id;
+#pragma unroll
+    for (int j = KL - 1; j > 0; --j) {
+        const float lo = ls[j], hi = ls[j - 1];
+        const int ilo = li[j], ihi = li[j - 1];
+        const bool sw = ranks_before(lo, ilo, hi, ihi);
+        ls[j - 1] = sw ? lo : hi;
+        ls[j] = sw ? hi : lo;
+        li[j - 1] = sw ? ilo : ihi;
+        li[j] = sw ? ihi : ilo;
+    }
+}
+
+struct MergeArgs {
+    const float* part_s; // [nq_pad][nsplit][2][KL]
+    const int* part_i;
+    int ncand;            // nsplit * 2 * KL
+    const uint16_t* docs; // [cap][ld]
+    const uint16_t* qbuf; // [nq_pad][ld]
+    int ld;
+    int k;
+    int metric;
+    double phi;
+    int64_t idx_offset;
+    float* out_s; // [nq][k]
+    int64_t* out_i;
+};
+
+// One wave per query.
+//  1. every lane folds its strided share of the query's candidate lists into a private sorted K-list
+//     (full comparator: candidates do not arrive in index order here);
+//  2. KL rounds of wave-wide arg-best pop the K best candidates by MFMA score; lane r keeps the r-th;
+//  3. lanes 0..KL-1 re-score their candidate exactly: sequential fp64 sum over k of q[k]*x[k] on the
+//     stored bf16 values (each product is exact in fp64, so the result does not depend on FMA
+//     contraction), cast to float -- the canonical score of include/mips_hip.h;
+//  4. rank the K candidates by (canonical score desc, idx asc) [L2: distance asc] and write the top k.
+template <int KL>
+__global__ __launch_bounds__(64) void merge_rerank_kernel(MergeArgs p) {
+    const int q = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float* ps = p.part_s + (size_t)q * p.ncand;
+    const int* pi = p.part_i + (size_t)q * p.ncand;
+
+    float ls[KL];
+    int li[KL];
+#pragma unroll
+    for (int i = 0; i < KL; ++i) {
+        ls[i] = -INFINITY;
+        li[i] = IDX_NONE;
+    }
+    for (int c = lane; c < p.ncand; c += 64) {
+        const float s = ps[c];
+        const int id = pi[c];
+        if (ranks_before(s, id, ls[KL - 1], li[KL - 1])) list_insert_full<KL>(ls, li, s, id);
+    }
+
+    float cs = -INFINITY;
+    int ci = IDX_NONE;
+    for (int r = 0; r < KL; ++r) {
+        const float hs = ls[0];
+        const int hi = li[0];
+        float bs = hs;
+        int bi = hi;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float os = __shfl_xor(bs, off);
+            const int oi = __shfl_xor(bi, off);
+            if (ranks_before(os, oi, bs, bi)) {
+                bs = os;
+                bi = oi;
+            }
+        }
+        if (hs == bs && hi == bi) { // the owner pops its head (document ids are unique across lists)
+#pragma unroll
+            for (int i = 0; i + 1 < KL; ++i) {
+                ls[i] = ls[i + 1];
+                li[i] = li[i + 1];
+            }
+            ls[KL - 1] = -INFINITY;
+            li[KL - 1] = IDX_NONE;
+        }
+        if (lane == r) {
+            cs = bs;
+            ci = bi;
+        }
+    }
+
+    const bool valid = lane < KL && ci != IDX_NONE;
+    double dot = 0.0, qq = 0.0;
+    if (valid) {
+        const uint16_t* x = p.docs + (size_t)ci * p.ld;
+        const uint16_t* y = p.qbuf + (size_t)q * p.ld;
+        for (int c = 0; c < p.ld; c += 8) {
+            const u32x4 xv = *reinterpret_cast<const u32x4*>(x + c);
+            const u32x4 yv = *reinterpret_cast<const u32x4*>(y + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double x0 = (double)bf16_bits_to_f32(xv[e] & 0xffffu);
+                const double x1 = (double)bf16_bits_to_f32(xv[e] >> 16);
+                const double y0 = (double)bf16_bits_to_f32(yv[e] & 0xffffu);
+                const double y1 = (double)bf16_bits_to_f32(yv[e] >> 16);
+                dot += x0 * y0;
+                dot += x1 * y1;
+                qq += y0 * y0;
+                qq += y1 * y1;
+            }
+        }
+    }
+    float outv, key;
+    if (p.metric == 1) { // L2 on phi-augmented vectors: |q|^2 + phi - 2 q.x, smaller is better
+        outv = (float)(qq + p.phi - 2.0 * dot);
+        key = -outv;
+    } else {
+        outv = (float)dot;
+        key = outv;
+    }
+    if (!valid) key = -INFINITY;
+    (void)cs;
+
+    int rank = 0;
+#pragma unroll
+    for (int jj = 0; jj < KL; ++jj) {
+        const float ok = __shfl(key, jj);
+        const int oi = __shfl(ci, jj);
+        if (oi != IDX_NONE && ranks_before(ok, oi, key, ci)) ++rank;
+    }
+    const int nvalid = __popcll(__ballot(valid));
+    if (valid && rank < p.k) {
+        p.out_s[(size_t)q * p.k + rank] = outv;
+        p.out_i[(size_t)q * p.k + rank] = (int64_t)ci + p.idx_offset;
+    }
+    if (lane < p.k && lane >= nvalid) {
+        p.out_s[(size_t)q * p.k + lane] = p.metric == 1 ? INFINITY : -INFINITY;
+        p.out_i[(size_t)q * p.k + lane] = -1;
+    }
+}
+
+// ------------------------------------------------------------------ cross-shard merge (after the all-gather)
+// One wave per query; rank by counting.  cand: [nq][c] with c = parts * k <= a few hundred.
+__global__ __launch_bounds__(64) void merge_topk_kernel(const float* cand_s, const int64_t* cand_i, int c, int k,
+                                                        int metric, float* out_s, int64_t* out_i) {
+    const int q = blockIdx.x;
+    const float* s = cand_s + (size_t)q * c;
+    const int64_t* id = cand_i + (size_t)q * c;
+    for (int a = threadIdx.x; a < c; a += 64) {
+        const float sa = metric == 1 ? -s[a] : s[a];
+        const int64_t ia = id[a] < 0 ? INT64_MAX : id[a];
+        int rank = 0;
+        for (int b = 0; b < c; ++b) {
+            const float sb = metric == 1 ? -s[b] : s[b];
+            const int64_t ib = id[b] < 0 ? INT64_MAX : id[b];
+            const bool before = sb > sa || (sb == sa && (ib < ia || (ib == ia && b < a)));
+            rank += before ? 1 : 0;
+        }
+        if (rank < k) {
+            out_s[(size_t)q * k + rank] = s[a];
+            out_i[(size_t)q * k + rank] = id[a];
+        }
+    }
+}
+
+__global__ void fill_empty_kernel(float* out_s, int64_t* out_i, int64_t total, int metric) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < total) {
+        out_s[t] = metric == 1 ? INFINITY : -INFINITY;
+        out_i[t] = -1;
+    }
+}
+
+} // namespace mips

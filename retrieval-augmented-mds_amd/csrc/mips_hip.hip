@@ -1,0 +1,502 @@
+// C ABI of the MI355X MIPS backend (include/mips_hip.h): index storage in HBM, host-side
+// orchestration of the fused scan + merge kernels.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/mips_hip.h"
+#include "aux_kernels.hpp"
+#include "scan_kernel.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? MIPS_E_NOMEM : MIPS_E_HIP, "%s failed: %s", \
+                        #expr, hipGetErrorString(e_));                                         \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+struct Buffer {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return MIPS_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = need + need / 4;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(MIPS_E_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        }
+        bytes = want;
+        return MIPS_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+int grid_for(int64_t items, int block) {
+    int64_t g = (items + block - 1) / block;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, 256 * 16));
+}
+
+} // namespace
+
+struct mips_index {
+    int device = 0;
+    int64_t d = 0;
+    int ld = 0; // d padded to a multiple of BK
+    int doc_dtype = MIPS_DTYPE_BF16;
+    int metric = MIPS_METRIC_IP;
+    int64_t ntotal = 0;
+    int64_t capacity = 0; // rows allocated, multiple of TM
+    uint16_t* rows = nullptr;
+    bool phi_valid = false;
+    double phi = 0.0;
+    Buffer qbuf, part_s, part_i, stage, out_s, out_i, scalar;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+namespace {
+
+int grow(mips_index* ix, int64_t need_rows, hipStream_t st) {
+    if (need_rows <= ix->capacity) return MIPS_OK;
+    int64_t cap = std::max<int64_t>(need_rows, ix->capacity + ix->capacity / 2);
+    cap = round_up(cap, mips::TM);
+    uint16_t* fresh = nullptr;
+    const size_t bytes = (size_t)cap * ix->ld * sizeof(uint16_t);
+    hipError_t e = hipMalloc((void**)&fresh, bytes);
+    if (e != hipSuccess) return fail(MIPS_E_NOMEM, "hipMalloc(%zu) for the index failed: %s", bytes, hipGetErrorString(e));
+    if (ix->ntotal > 0)
+        HIP_TRY(hipMemcpyAsync(fresh, ix->rows, (size_t)ix->ntotal * ix->ld * 2, hipMemcpyDeviceToDevice, st));
+    // rows past ntotal are read by the last (ragged) tile: keep them defined
+    const size_t used = (size_t)ix->ntotal * ix->ld * 2;
+    HIP_TRY(hipMemsetAsync((char*)fresh + used, 0, bytes - used, st));
+    if (ix->rows) {
+        HIP_TRY(hipStreamSynchronize(st));
+        (void)hipFree(ix->rows);
+    }
+    ix->rows = fresh;
+    ix->capacity = cap;
+    return MIPS_OK;
+}
+
+// convert [n][d] of src_dtype (host or device) into dst [n][ld] bf16 on the device
+int convert_into(mips_index* ix, const void* src, int64_t n, int src_dtype, int src_is_device, uint16_t* dst,
+                 hipStream_t st) {
+    const int d = (int)ix->d, ld = ix->ld;
+    const size_t esz = src_dtype == MIPS_DTYPE_F32 ? 4 : 2;
+    const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(64u << 20) / (int64_t)(d * esz));
+    for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
+        const int64_t nr = std::min(chunk_rows, n - r0);
+        const void* s = (const char*)src + (size_t)r0 * d * esz;
+        if (!src_is_device) {
+            int rc = ix->stage.ensure((size_t)nr * d * esz);
+            if (rc) return rc;
+            // the staging buffer is reused by the next chunk: this copy is synchronous for pageable memory
+            HIP_TRY(hipMemcpyAsync(ix->stage.p, s, (size_t)nr * d * esz, hipMemcpyHostToDevice, st));
+            s = ix->stage.p;
+        }
+        const int64_t items = nr * (ld / 8);
+        if (src_dtype == MIPS_DTYPE_F32)
+            mips::convert_rows_kernel<float><<<grid_for(items, 256), 256, 0, st>>>((const float*)s, nr, d, dst + r0 * ld, ld);
+        else
+            mips::convert_rows_kernel<uint16_t><<<grid_for(items, 256), 256, 0, st>>>((const uint16_t*)s, nr, d, dst + r0 * ld, ld);
+        HIP_TRY(hipGetLastError());
+        if (!src_is_device) HIP_TRY(hipStreamSynchronize(st));
+    }
+    return MIPS_OK;
+}
+
+int compute_phi(mips_index* ix, hipStream_t st) {
+    if (ix->phi_valid) return MIPS_OK;
+    int rc = ix->scalar.ensure(16);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ix->scalar.p, 0, 8, st));
+    if (ix->ntotal > 0) {
+        mips::row_sumsq_max_kernel<<<(int)((ix->ntotal + 255) / 256), 256, 0, st>>>(ix->rows, ix->ntotal, ix->ld,
+                                                                                    (unsigned long long*)ix->scalar.p);
+        HIP_TRY(hipGetLastError());
+    }
+    unsigned long long bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, ix->scalar.p, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::memcpy(&ix->phi, &bits, 8);
+    ix->phi_valid = true;
+    return MIPS_OK;
+}
+
+template <int KL>
+int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_out_i, int64_t idx_offset,
+                  hipStream_t st) {
+    const int64_t nq_pad = round_up(nq, mips::TN);
+    const int nqt = (int)(nq_pad / mips::TN);
+    const int ntiles = (int)((ix->ntotal + mips::TM - 1) / mips::TM);
+    // enough workgroups for two per CU; splits are a multiple of 8 (one XCD group each)
+    int nsplit = (int)round_up(std::max(1, (512 + nqt - 1) / nqt), 8);
+    nsplit = (int)std::min<int64_t>(nsplit, round_up(ntiles, 8));
+    const int tps = (ntiles + nsplit - 1) / nsplit;
+
+    const size_t ncand = (size_t)nsplit * 2 * KL;
+    int rc = ix->part_s.ensure((size_t)nq_pad * ncand * sizeof(float));
+    if (rc) return rc;
+    rc = ix->part_i.ensure((size_t)nq_pad * ncand * sizeof(int));
+    if (rc) return rc;
+
+    mips::ScanArgs a;
+    a.docs = ix->rows;
+    a.qbuf = (const uint16_t*)ix->qbuf.p;
+    a.ntotal = ix->ntotal;
+    a.ld = ix->ld;
+    a.ksteps = ix->ld / mips::BK;
+    a.ntiles = ntiles;
+    a.tiles_per_split = tps;
+    a.nsplit = nsplit;
+    a.nqt = nqt;
+    a.part_s = (float*)ix->part_s.p;
+    a.part_i = (int*)ix->part_i.p;
+
+    HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel<KL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                mips::SCAN_LDS_BYTES));
+    HIP_TRY(hipEventRecord(ix->ev0, st));
+    mips::scan_kernel<KL><<<nqt * nsplit, mips::SCAN_THREADS, mips::SCAN_LDS_BYTES, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ix->ev1, st));
+    ix->timed = true;
+
+    mips::MergeArgs m;
+    m.part_s = a.part_s;
+    m.part_i = a.part_i;
+    m.ncand = (int)ncand;
+    m.docs = ix->rows;
+    m.qbuf = a.qbuf;
+    m.ld = ix->ld;
+    m.k = k;
+    m.metric = ix->metric;
+    m.phi = ix->phi;
+    m.idx_offset = idx_offset;
+    m.out_s = d_out_s;
+    m.out_i = d_out_i;
+    mips::merge_rerank_kernel<KL><<<(int)nq, 64, 0, st>>>(m);
+    HIP_TRY(hipGetLastError());
+    return MIPS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int mips_abi_version(void) { return MIPS_ABI_VERSION; }
+
+const char* mips_last_error(void) { return g_err.c_str(); }
+
+int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, int metric) {
+    if (!out) return fail(MIPS_E_INVALID, "mips_index_create: out is NULL");
+    *out = nullptr;
+    if (d <= 0 || d > (1 << 20)) return fail(MIPS_E_INVALID, "mips_index_create: bad dimension %lld", (long long)d);
+    if (metric != MIPS_METRIC_IP && metric != MIPS_METRIC_L2)
+        return fail(MIPS_E_INVALID, "mips_index_create: metric must be 0 (inner product) or 1 (L2), got %d", metric);
+    if (doc_dtype == MIPS_DTYPE_FP8_E4M3)
+        return fail(MIPS_E_UNSUPPORTED, "mips_index_create: fp8 e4m3 index storage is not implemented in this build");
+    if (doc_dtype != MIPS_DTYPE_BF16)
+        return fail(MIPS_E_INVALID, "mips_index_create: index storage dtype must be MIPS_DTYPE_BF16, got %d", doc_dtype);
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(MIPS_E_INVALID, "mips_index_create: no HIP device %d (have %d)", device, count);
+    DeviceGuard g(device);
+    if (!g.ok) return fail(MIPS_E_HIP, "hipSetDevice(%d) failed", device);
+    mips_index* ix = new (std::nothrow) mips_index();
+    if (!ix) return fail(MIPS_E_NOMEM, "out of host memory");
+    ix->device = device;
+    ix->d = d;
+    ix->ld = (int)round_up(d, mips::BK);
+    ix->doc_dtype = doc_dtype;
+    ix->metric = metric;
+    if (hipEventCreate(&ix->ev0) != hipSuccess || hipEventCreate(&ix->ev1) != hipSuccess) {
+        delete ix;
+        return fail(MIPS_E_HIP, "hipEventCreate failed");
+    }
+    *out = ix;
+    return MIPS_OK;
+}
+
+int mips_index_destroy(mips_index_t* ix) {
+    if (!ix) return MIPS_OK;
+    DeviceGuard g(ix->device);
+    (void)hipDeviceSynchronize();
+    if (ix->rows) (void)hipFree(ix->rows);
+    ix->qbuf.release();
+    ix->part_s.release();
+    ix->part_i.release();
+    ix->stage.release();
+    ix->out_s.release();
+    ix->out_i.release();
+    ix->scalar.release();
+    if (ix->ev0) (void)hipEventDestroy(ix->ev0);
+    if (ix->ev1) (void)hipEventDestroy(ix->ev1);
+    delete ix;
+    return MIPS_OK;
+}
+
+int mips_index_reserve(mips_index_t* ix, int64_t n) {
+    if (!ix || n < 0) return fail(MIPS_E_INVALID, "mips_index_reserve: bad argument");
+    DeviceGuard g(ix->device);
+    if (n <= ix->capacity) return MIPS_OK;
+    // exact reservation (no geometric slack)
+    int64_t cap = round_up(n, mips::TM);
+    uint16_t* fresh = nullptr;
+    const size_t bytes = (size_t)cap * ix->ld * 2;
+    hipError_t e = hipMalloc((void**)&fresh, bytes);
+    if (e != hipSuccess) return fail(MIPS_E_NOMEM, "hipMalloc(%zu) for the index failed: %s", bytes, hipGetErrorString(e));
+    const size_t used = (size_t)ix->ntotal * ix->ld * 2;
+    if (used) HIP_TRY(hipMemcpy(fresh, ix->rows, used, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemset((char*)fresh + used, 0, bytes - used));
+    if (ix->rows) (void)hipFree(ix->rows);
+    ix->rows = fresh;
+    ix->capacity = cap;
+    return MIPS_OK;
+}
+
+int mips_index_add(mips_index_t* ix, const void* rows, int64_t n, int src_dtype, int src_is_device, void* hip_stream) {
+    if (!ix) return fail(MIPS_E_INVALID, "mips_index_add: index is NULL");
+    if (n < 0 || (n > 0 && !rows)) return fail(MIPS_E_INVALID, "mips_index_add: bad rows / n");
+    if (src_dtype != MIPS_DTYPE_F32 && src_dtype != MIPS_DTYPE_BF16)
+        return fail(MIPS_E_INVALID, "mips_index_add: src_dtype must be F32 or BF16");
+    if (n == 0) return MIPS_OK;
+    if (ix->ntotal + n > (int64_t)0x7fffff00) return fail(MIPS_E_UNSUPPORTED, "mips_index_add: more than 2^31 rows on one GPU");
+    DeviceGuard g(ix->device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    int rc = grow(ix, ix->ntotal + n, st);
+    if (rc) return rc;
+    rc = convert_into(ix, rows, n, src_dtype, src_is_device, ix->rows + (size_t)ix->ntotal * ix->ld, st);
+    if (rc) return rc;
+    ix->ntotal += n;
+    ix->phi_valid = false;
+    return MIPS_OK;
+}
+
+int mips_index_reset(mips_index_t* ix) {
+    if (!ix) return fail(MIPS_E_INVALID, "mips_index_reset: index is NULL");
+    ix->ntotal = 0;
+    ix->phi_valid = false;
+    return MIPS_OK;
+}
+
+int64_t mips_index_ntotal(const mips_index_t* ix) { return ix ? ix->ntotal : -1; }
+int64_t mips_index_dim(const mips_index_t* ix) { return ix ? ix->d : -1; }
+int mips_index_metric(const mips_index_t* ix) { return ix ? ix->metric : -1; }
+
+int mips_index_phi(mips_index_t* ix, double* out_phi, void* hip_stream) {
+    if (!ix || !out_phi) return fail(MIPS_E_INVALID, "mips_index_phi: bad argument");
+    DeviceGuard g(ix->device);
+    int rc = compute_phi(ix, (hipStream_t)hip_stream);
+    if (rc) return rc;
+    *out_phi = ix->phi;
+    return MIPS_OK;
+}
+
+int mips_index_read_rows(mips_index_t* ix, int64_t row0, int64_t n, void* out_host_u16, void* hip_stream) {
+    if (!ix || row0 < 0 || n < 0 || row0 + n > ix->ntotal || (n > 0 && !out_host_u16))
+        return fail(MIPS_E_INVALID, "mips_index_read_rows: bad range [%lld, +%lld) of %lld", (long long)row0, (long long)n,
+                    ix ? (long long)ix->ntotal : -1LL);
+    if (n == 0) return MIPS_OK;
+    DeviceGuard g(ix->device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipMemcpy2DAsync(out_host_u16, (size_t)ix->d * 2, ix->rows + (size_t)row0 * ix->ld, (size_t)ix->ld * 2,
+                             (size_t)ix->d * 2, (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return MIPS_OK;
+}
+
+int mips_index_add_synthetic(mips_index_t* ix, int64_t n, int64_t row0, uint64_t seed, int kind, void* hip_stream) {
+    if (!ix || n < 0 || row0 < 0) return fail(MIPS_E_INVALID, "mips_index_add_synthetic: bad argument");
+    if (kind < 0 || kind > 2) return fail(MIPS_E_INVALID, "mips_index_add_synthetic: unknown kind %d", kind);
+    if (n == 0) return MIPS_OK;
+    if (ix->ntotal + n > (int64_t)0x7fffff00) return fail(MIPS_E_UNSUPPORTED, "more than 2^31 rows on one GPU");
+    DeviceGuard g(ix->device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    int rc = grow(ix, ix->ntotal + n, st);
+    if (rc) return rc;
+    const int64_t items = n * (ix->ld / 8);
+    mips::synth_fill_kernel<<<grid_for(items, 256), 256, 0, st>>>(ix->rows + (size_t)ix->ntotal * ix->ld, n, (int)ix->d,
+                                                                  ix->ld, row0, seed, kind, 0);
+    HIP_TRY(hipGetLastError());
+    ix->ntotal += n;
+    ix->phi_valid = false;
+    return MIPS_OK;
+}
+
+int mips_synth_fill(void* out_device, int64_t n, int64_t d, int64_t row0, uint64_t seed, int kind, int dtype, int device,
+                    void* hip_stream) {
+    if (!out_device || n < 0 || d <= 0 || d % 8 != 0)
+        return fail(MIPS_E_INVALID, "mips_synth_fill: bad argument (d must be a positive multiple of 8)");
+    if (kind < 0 || kind > 2) return fail(MIPS_E_INVALID, "mips_synth_fill: unknown kind %d", kind);
+    if (dtype != MIPS_DTYPE_F32 && dtype != MIPS_DTYPE_BF16) return fail(MIPS_E_INVALID, "mips_synth_fill: dtype must be F32 or BF16");
+    if (n == 0) return MIPS_OK;
+    DeviceGuard g(device);
+    if (!g.ok) return fail(MIPS_E_HIP, "hipSetDevice(%d) failed", device);
+    const int64_t items = n * (d / 8);
+    mips::synth_fill_kernel<<<grid_for(items, 256), 256, 0, (hipStream_t)hip_stream>>>(out_device, n, (int)d, (int)d, row0, seed,
+                                                                                      kind, dtype == MIPS_DTYPE_F32 ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return MIPS_OK;
+}
+
+int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k, float* out_scores, int64_t* out_idx,
+                int64_t idx_offset, int flags, void* hip_stream) {
+    if (!ix) return fail(MIPS_E_INVALID, "mips_search: index is NULL");
+    if (nq < 0 || k < 0) return fail(MIPS_E_INVALID, "mips_search: negative nq or k");
+    if (k > MIPS_MAX_K) return fail(MIPS_E_UNSUPPORTED, "mips_search: k = %d exceeds MIPS_MAX_K = %d", k, MIPS_MAX_K);
+    if (q_dtype != MIPS_DTYPE_F32 && q_dtype != MIPS_DTYPE_BF16) return fail(MIPS_E_INVALID, "mips_search: q_dtype must be F32 or BF16");
+    if (nq == 0 || k == 0) return MIPS_OK;
+    if (!q || !out_scores || !out_idx) return fail(MIPS_E_INVALID, "mips_search: NULL buffer");
+    if (nq > (1 << 24)) return fail(MIPS_E_UNSUPPORTED, "mips_search: more than 2^24 queries in one call");
+    DeviceGuard g(ix->device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const bool out_dev = (flags & MIPS_OUT_DEVICE) != 0;
+
+    float* d_s = out_scores;
+    int64_t* d_i = out_idx;
+    if (!out_dev) {
+        int rc = ix->out_s.ensure((size_t)nq * k * sizeof(float));
+        if (rc) return rc;
+        rc = ix->out_i.ensure((size_t)nq * k * sizeof(int64_t));
+        if (rc) return rc;
+        d_s = (float*)ix->out_s.p;
+        d_i = (int64_t*)ix->out_i.p;
+    }
+
+    ix->timed = false;
+    if (ix->ntotal == 0) {
+        const int64_t total = nq * k;
+        mips::fill_empty_kernel<<<(int)((total + 255) / 256), 256, 0, st>>>(d_s, d_i, total, ix->metric);
+        HIP_TRY(hipGetLastError());
+    } else {
+        if (ix->metric == MIPS_METRIC_L2) {
+            int rc = compute_phi(ix, st);
+            if (rc) return rc;
+        }
+        const int64_t nq_pad = round_up(nq, mips::TN);
+        int rc = ix->qbuf.ensure((size_t)nq_pad * ix->ld * 2);
+        if (rc) return rc;
+        uint16_t* qb = (uint16_t*)ix->qbuf.p;
+        rc = convert_into(ix, q, nq, q_dtype, (flags & MIPS_Q_DEVICE) ? 1 : 0, qb, st);
+        if (rc) return rc;
+        if (nq_pad > nq) {
+            const int64_t items = (nq_pad - nq) * (ix->ld / 8);
+            mips::zero_rows_kernel<<<grid_for(items, 256), 256, 0, st>>>(qb + (size_t)nq * ix->ld, nq_pad - nq, ix->ld);
+            HIP_TRY(hipGetLastError());
+        }
+        if (k <= 5)
+            rc = launch_search<8>(ix, nq, k, d_s, d_i, idx_offset, st);
+        else if (k <= 13)
+            rc = launch_search<16>(ix, nq, k, d_s, d_i, idx_offset, st);
+        else
+            rc = launch_search<32>(ix, nq, k, d_s, d_i, idx_offset, st);
+        if (rc) return rc;
+    }
+    if (!out_dev) {
+        HIP_TRY(hipMemcpyAsync(out_scores, d_s, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out_idx, d_i, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return MIPS_OK;
+}
+
+int mips_merge_topk(const float* cand_s, const int64_t* cand_i, int64_t nq, int parts, int k, int metric, float* out_s,
+                    int64_t* out_i, int device, void* hip_stream) {
+    if (nq < 0 || parts <= 0 || k < 0) return fail(MIPS_E_INVALID, "mips_merge_topk: bad sizes");
+    if (nq == 0 || k == 0) return MIPS_OK;
+    if (!cand_s || !cand_i || !out_s || !out_i) return fail(MIPS_E_INVALID, "mips_merge_topk: NULL buffer");
+    if ((int64_t)parts * k > 65536) return fail(MIPS_E_UNSUPPORTED, "mips_merge_topk: parts * k too large");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(MIPS_E_HIP, "hipSetDevice(%d) failed", device);
+    mips::merge_topk_kernel<<<(int)nq, 64, 0, (hipStream_t)hip_stream>>>(cand_s, cand_i, parts * k, k, metric, out_s, out_i);
+    HIP_TRY(hipGetLastError());
+    return MIPS_OK;
+}
+
+int mips_l2_normalize(float* x_device, int64_t n, int64_t d, int device, void* hip_stream) {
+    if (n < 0 || d <= 0 || (n > 0 && !x_device)) return fail(MIPS_E_INVALID, "mips_l2_normalize: bad argument");
+    if (n == 0) return MIPS_OK;
+    DeviceGuard g(device);
+    if (!g.ok) return fail(MIPS_E_HIP, "hipSetDevice(%d) failed", device);
+    mips::l2_normalize_kernel<<<(int)((n + 3) / 4), 256, 0, (hipStream_t)hip_stream>>>(x_device, n, (int)d);
+    HIP_TRY(hipGetLastError());
+    return MIPS_OK;
+}
+
+int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out_host, int device, void* hip_stream) {
+    if (n < 0 || d <= 0 || (n > 0 && !x_device) || !out_host) return fail(MIPS_E_INVALID, "mips_rows_max_sumsq: bad argument");
+    *out_host = 0.0;
+    if (n == 0) return MIPS_OK;
+    DeviceGuard g(device);
+    if (!g.ok) return fail(MIPS_E_HIP, "hipSetDevice(%d) failed", device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    unsigned long long* slot = nullptr;
+    HIP_TRY(hipMalloc((void**)&slot, 8));
+    hipError_t e = hipMemsetAsync(slot, 0, 8, st);
+    if (e == hipSuccess) {
+        mips::f32_rows_max_sumsq_kernel<<<(int)((n + 3) / 4), 256, 0, st>>>(x_device, n, (int)d, slot);
+        e = hipGetLastError();
+    }
+    unsigned long long bits = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&bits, slot, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(slot);
+    if (e != hipSuccess) return fail(MIPS_E_HIP, "mips_rows_max_sumsq: %s", hipGetErrorString(e));
+    std::memcpy(out_host, &bits, 8);
+    return MIPS_OK;
+}
+
+int mips_last_scan_ms(mips_index_t* ix, float* out_ms) {
+    if (!ix || !out_ms) return fail(MIPS_E_INVALID, "mips_last_scan_ms: bad argument");
+    *out_ms = -1.f;
+    if (!ix->timed) return MIPS_OK;
+    DeviceGuard g(ix->device);
+    HIP_TRY(hipEventElapsedTime(out_ms, ix->ev0, ix->ev1));
+    return MIPS_OK;
+}
+
+} // extern "C"

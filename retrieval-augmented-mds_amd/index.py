@@ -1,0 +1,266 @@
+"""MipsIndex -- the faiss.IndexFlat-shaped object the reference reaches through
+`self.embeddings.get_index(self.index_name).faiss_index` (sotasum/mips.py:383-386, 342-345).
+
+Duck type kept:  d, ntotal, metric_type, nprobe (settable, ignored: the index is exact),
+add(x), search(x, k) -> (D float32 [nq,k], I int64 [nq,k]), reset().
+Extensions: torch CUDA tensors in -> torch CUDA tensors out (no host hop), add_synthetic,
+save/load of the raw bf16 shard, last_scan_ms for the bench.
+
+All arithmetic happens in libmips_hip.so (hand-written HIP, gfx950); this file only moves
+pointers.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+import threading
+
+import numpy as np
+
+from . import _lib
+
+_FORMAT_VERSION = 1
+
+
+def _stream_handle(device: int) -> int:
+    import torch
+
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+class MipsIndex:
+    def __init__(self, d: int, metric: int = _lib.METRIC_IP, dtype: str = "bf16", device: int | None = None):
+        if dtype != "bf16":
+            raise NotImplementedError(f"index dtype {dtype!r}: this build stores bf16 only")
+        self._lib = _lib.load()
+        self.device = _lib.require_gpu(device)
+        self._h = ctypes.c_void_p()
+        _lib.check(self._lib.mips_index_create(ctypes.byref(self._h), self.device, int(d), _lib.DTYPE_BF16,
+                                               int(metric)), "mips_index_create")
+        self._d = int(d)
+        self._metric = int(metric)
+        self.dtype = dtype
+        self.nprobe = 1  # accepted for drop-in compatibility (mips.py:342-345); exact search ignores it
+        self._mutex = threading.Lock()
+
+    # ------------------------------------------------------------------ faiss-like attributes
+    @property
+    def d(self) -> int:
+        return self._d
+
+    @property
+    def ntotal(self) -> int:
+        return int(self._lib.mips_index_ntotal(self._h))
+
+    @property
+    def metric_type(self) -> int:
+        return self._metric
+
+    is_trained = True
+
+    def __len__(self) -> int:
+        return self.ntotal
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                self._lib.mips_index_destroy(h)
+            except Exception:
+                pass
+            h.value = None
+
+    # ------------------------------------------------------------------ helpers
+    def _as_buffer(self, x, what: str):
+        """-> (pointer, dtype code, is_device, n, keepalive)"""
+        import torch
+
+        if isinstance(x, torch.Tensor):
+            if x.dim() != 2 or x.shape[1] != self._d:
+                raise ValueError(f"{what}: expected [n, {self._d}], got {tuple(x.shape)}")
+            if x.dtype == torch.float32:
+                code = _lib.DTYPE_F32
+            elif x.dtype == torch.bfloat16:
+                code = _lib.DTYPE_BF16
+            else:
+                x = x.float()
+                code = _lib.DTYPE_F32
+            x = x.contiguous()
+            if x.is_cuda:
+                if x.device.index != self.device:
+                    x = x.to(f"cuda:{self.device}")
+                return x.data_ptr(), code, 1, x.shape[0], x
+            return x.data_ptr(), code, 0, x.shape[0], x
+        a = np.asarray(x)
+        if a.ndim != 2 or a.shape[1] != self._d:
+            raise ValueError(f"{what}: expected [n, {self._d}], got {a.shape}")
+        if a.dtype == np.uint16:  # raw bf16 bit patterns
+            a = np.ascontiguousarray(a)
+            return a.ctypes.data, _lib.DTYPE_BF16, 0, a.shape[0], a
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        return a.ctypes.data, _lib.DTYPE_F32, 0, a.shape[0], a
+
+    # ------------------------------------------------------------------ building
+    def reserve(self, n: int) -> None:
+        _lib.check(self._lib.mips_index_reserve(self._h, int(n)), "mips_index_reserve")
+
+    def add(self, x) -> None:
+        """faiss Index.add: append rows (np.float32 / np.uint16 bf16 bits / torch float32|bfloat16,
+        host or device).  float32 is rounded to bf16 (RNE) on the device."""
+        ptr, code, is_dev, n, keep = self._as_buffer(x, "add")
+        with self._mutex:
+            _lib.check(self._lib.mips_index_add(self._h, ptr, n, code, is_dev, _stream_handle(self.device)),
+                       "mips_index_add")
+        del keep
+
+    def add_synthetic(self, n: int, row0: int = 0, seed: int = 0xD0C5, kind: int = _lib.SYNTH_GAUSS) -> None:
+        with self._mutex:
+            _lib.check(self._lib.mips_index_add_synthetic(self._h, int(n), int(row0), int(seed), int(kind),
+                                                          _stream_handle(self.device)), "mips_index_add_synthetic")
+
+    def reset(self) -> None:
+        _lib.check(self._lib.mips_index_reset(self._h), "mips_index_reset")
+
+    def phi(self) -> float:
+        out = ctypes.c_double()
+        _lib.check(self._lib.mips_index_phi(self._h, ctypes.byref(out), _stream_handle(self.device)), "mips_index_phi")
+        return out.value
+
+    def rows_bf16(self, row0: int = 0, n: int | None = None) -> np.ndarray:
+        """Stored rows as bf16 bit patterns, np.uint16 [n, d]."""
+        n = self.ntotal - row0 if n is None else n
+        out = np.empty((n, self._d), dtype=np.uint16)
+        _lib.check(self._lib.mips_index_read_rows(self._h, int(row0), int(n), out.ctypes.data,
+                                                  _stream_handle(self.device)), "mips_index_read_rows")
+        return out
+
+    # ------------------------------------------------------------------ search
+    def search(self, x, k: int, idx_offset: int = 0):
+        """faiss Index.search(x, k) -> (D, I)  (sotasum/mips.py:383-386).
+        NumPy in -> NumPy out; torch CUDA tensor in -> torch CUDA tensors out (stream-ordered, no
+        synchronisation)."""
+        import torch
+
+        k = int(k)
+        if k < 0:
+            raise ValueError("k must be >= 0")
+        if k > _lib.MAX_K:
+            raise NotImplementedError(f"k = {k} > {_lib.MAX_K} is not supported by this build")
+        ptr, code, is_dev, nq, keep = self._as_buffer(x, "search")
+        stream = _stream_handle(self.device)
+        if is_dev:
+            dev = f"cuda:{self.device}"
+            D = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+            flags = _lib.Q_DEVICE | _lib.OUT_DEVICE
+            ds, di = D.data_ptr(), I.data_ptr()
+        else:
+            D = np.empty((nq, k), dtype=np.float32)
+            I = np.empty((nq, k), dtype=np.int64)
+            flags = 0
+            ds, di = D.ctypes.data, I.ctypes.data
+        with self._mutex:
+            _lib.check(self._lib.mips_search(self._h, ptr, code, nq, k, ds, di, int(idx_offset), flags, stream),
+                       "mips_search")
+        del keep
+        return D, I
+
+    def last_scan_ms(self) -> float:
+        out = ctypes.c_float()
+        _lib.check(self._lib.mips_last_scan_ms(self._h, ctypes.byref(out)), "mips_last_scan_ms")
+        return out.value
+
+    # ------------------------------------------------------------------ persistence
+    # Own format (the on-disk format is free, the call surface is kept):
+    #   <path>/meta.json   {"format":1,"d":..,"ntotal":..,"metric":..,"dtype":"bf16", ...}
+    #   <path>/rows.bf16   raw little-endian bf16 bit patterns [ntotal, d]
+    def save(self, path: str, extra: dict | None = None, chunk_rows: int = 1 << 16) -> None:
+        """Replaces Dataset.save_faiss_index (sotasum/mips.py:536)."""
+        os.makedirs(path, exist_ok=True)
+        n = self.ntotal
+        with open(os.path.join(path, "rows.bf16"), "wb") as f:
+            for r0 in range(0, n, chunk_rows):
+                f.write(self.rows_bf16(r0, min(chunk_rows, n - r0)).tobytes())
+        meta = {"format": _FORMAT_VERSION, "d": self._d, "ntotal": n, "metric": self._metric, "dtype": self.dtype}
+        if extra:
+            meta.update(extra)
+        with open(os.path.join(path, "meta.json"), "w") as f:
+            json.dump(meta, f)
+
+    @classmethod
+    def load(cls, path: str, device: int | None = None, row_range: tuple | None = None,
+             chunk_rows: int = 1 << 16) -> "MipsIndex":
+        """Replaces Dataset.load_faiss_index (sotasum/mips.py:547).  row_range=(lo, hi) loads one
+        row shard of the file (multi-GPU: every rank maps the same file and keeps its own rows)."""
+        with open(os.path.join(path, "meta.json")) as f:
+            meta = json.load(f)
+        if meta.get("format") != _FORMAT_VERSION:
+            raise ValueError(f"unknown index format {meta.get('format')}")
+        ix = cls(meta["d"], metric=meta["metric"], dtype=meta["dtype"], device=device)
+        n, d = meta["ntotal"], meta["d"]
+        lo, hi = (0, n) if row_range is None else row_range
+        if hi > lo:
+            mm = np.memmap(os.path.join(path, "rows.bf16"), dtype=np.uint16, mode="r", shape=(n, d))
+            ix.reserve(hi - lo)
+            for r0 in range(lo, hi, chunk_rows):
+                ix.add(np.asarray(mm[r0:min(hi, r0 + chunk_rows)]))
+            del mm
+        ix.meta = meta
+        return ix
+
+
+def synth_fill(n: int, d: int, row0: int, seed: int, kind: int, dtype="bf16", device: int | None = None):
+    """Device tensor [n, d] of generator values (torch.bfloat16 or torch.float32)."""
+    import torch
+
+    lib = _lib.load()
+    dev = _lib.require_gpu(device)
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    out = torch.empty((n, d), dtype=tdt, device=f"cuda:{dev}")
+    _lib.check(lib.mips_synth_fill(out.data_ptr(), n, d, row0, seed, kind,
+                                   _lib.DTYPE_BF16 if dtype == "bf16" else _lib.DTYPE_F32, dev,
+                                   _stream_handle(dev)), "mips_synth_fill")
+    return out
+
+
+def l2_normalize_(x):
+    """In-place row normalisation of a CUDA float32 tensor (faiss.normalize_L2 semantics,
+    sotasum/mips.py:521-525)."""
+    import torch
+
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2):
+        raise ValueError("l2_normalize_: expected a contiguous CUDA float32 matrix")
+    lib = _lib.load()
+    _lib.check(lib.mips_l2_normalize(x.data_ptr(), x.shape[0], x.shape[1], x.device.index,
+                                     _stream_handle(x.device.index)), "mips_l2_normalize")
+    return x
+
+
+def rows_max_sumsq(x) -> float:
+    """max_i |x_i|^2 of a CUDA float32 matrix (its sqrt is max_norm, sotasum/mips.py:298-304)."""
+    import torch
+
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2):
+        raise ValueError("rows_max_sumsq: expected a contiguous CUDA float32 matrix")
+    lib = _lib.load()
+    out = ctypes.c_double()
+    _lib.check(lib.mips_rows_max_sumsq(x.data_ptr(), x.shape[0], x.shape[1], ctypes.byref(out), x.device.index,
+                                       _stream_handle(x.device.index)), "mips_rows_max_sumsq")
+    return out.value
+
+
+def merge_topk(cand_s, cand_i, parts: int, k: int, metric: int = _lib.METRIC_IP):
+    """Device merge of `parts` per-shard top-k lists: cand_* CUDA [nq, parts*k] -> ([nq,k], [nq,k])."""
+    import torch
+
+    lib = _lib.load()
+    nq = cand_s.shape[0]
+    cand_s = cand_s.contiguous()
+    cand_i = cand_i.contiguous()
+    dev = cand_s.device.index
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=cand_s.device)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=cand_s.device)
+    _lib.check(lib.mips_merge_topk(cand_s.data_ptr(), cand_i.data_ptr(), nq, parts, k, metric, out_s.data_ptr(),
+                                   out_i.data_ptr(), dev, _stream_handle(dev)), "mips_merge_topk")
+    return out_s, out_i

@@ -1,0 +1,369 @@
+"""`Mips` -- drop-in for the retrieval half of sotasum/mips.py:154-560 on the MI355X backend.
+
+Kept call surface (what retriever_generator.py:145-153 and lightning_model.py:148-180 call):
+    Mips(args)                      config knobs = the mips_* fields of sotasum/model_config.py:44-72
+    ._prepare_query(query)          mips.py:368-375
+    .search(queries, ignore_indexes, k)     mips.py:382-400 (k+1 fetch, equality filter, lists)
+    .forward(queries, aid, aid_counts, target_str, input_str, ignore_indexes, k)   mips.py:402-463
+    .build_index(...) / .save() / .load()   mips.py:290-345, 531-549
+    .l2_normalization(x), .np_search(x, k), .max_norm, .rebuilt_steps, .embeddings
+plus the module-level helpers get_phi / augment_xb / augment_xq (mips.py:55-70), inner_product
+(mips.py:552-560) and retriever_metrics (pretrain.py:69-85).
+
+Out of scope: the SPECTER2 / Longformer encoders that produce embeddings and
+re-encode retrieved texts (mips.py:87-151, 226-288, 465-519) -- they need hub weights.  `forward`
+therefore stops where the reference hands the retrieved texts to those encoders and returns the
+texts (`examples`, `flat_texts`) with the scores, metrics and prepared queries.
+
+The index itself is a MipsIndex (HIP, bf16 in HBM).  The reference's L2 mode searches
+phi-augmented (d+1)-dimensional vectors (mips.py:316-331, 371-372); the same ranking and the same
+squared distances are produced from the un-augmented d-dimensional index as |q|^2 + phi - 2 q.x, so
+the kernel stays an inner-product kernel.  `_prepare_query` still appends the zero column exactly
+like the reference; `search` strips it again.
+"""
+from __future__ import annotations
+
+import json
+import pickle
+import shutil
+from dataclasses import dataclass, field
+from pathlib import Path
+from random import random
+
+import numpy as np
+
+from . import _lib
+from .index import MipsIndex, l2_normalize_, rows_max_sumsq
+
+METRIC_INNER_PRODUCT = _lib.METRIC_IP
+METRIC_L2 = _lib.METRIC_L2
+
+
+@dataclass
+class MipsArgs:
+    """The subset of sotasum/model_config.py:4-82 this path reads (same names, same defaults)."""
+    mips_disabled: bool = False
+    mips_topk: int = 2
+    mips_string_factory: str = "Flat"
+    mips_nprobe: int = None
+    mips_rebuild_every: int = 10000
+    mips_train_size: int = -1
+    mips_metric_type: int = 0  # 0 -> INNER_PRODUCT ; 1 -> L2
+    mips_normalize: bool = True
+    mips_db_max_size: int = None
+    mips_tmp_folder: str = "./tmp"
+    mips_batch_size: int = 32
+    log_retriever_metrics: bool = False
+    memory_forcing: str = "no_forcing"
+    multi_x_science_dataset_mode: str = "original"
+    copy_forcing: float = 0.0
+    doc_sep: str = " <DOC_SEP> "
+    # backend knobs (not in the reference)
+    mips_index_dtype: str = "bf16"
+    mips_device: int = None
+
+
+@dataclass
+class MipsModelOutput:
+    """Carrier mirroring sotasum/mips.py:33-42 (encoder fields stay None: out of scope)."""
+    scores: object = None
+    mips_last_hidden_state: object = None
+    memory_outputs: dict = None
+    memory_input_ids: object = None
+    memory_attention_mask: object = None
+    metrics: dict = None
+    examples: list = None
+    query_cls: np.ndarray = None
+    indices: object = None      # extension: the retrieved row ids
+    flat_texts: list = None     # extension: what the reference tokenises next (mips.py:465)
+
+
+# --------------------------------------------------------------------------- module-level helpers
+def get_phi(xb: np.ndarray):
+    """max_i |x_i|^2 (mips.py:55-56)."""
+    return np.square(xb).sum(axis=1).max()
+
+
+def augment_xb(xb: np.ndarray, phi=None) -> np.ndarray:
+    """Append sqrt(phi - |x|^2) to every document (mips.py:59-65)."""
+    sq = np.square(xb).sum(axis=1)
+    if phi is None:
+        phi = sq.max()
+    return np.hstack((xb, np.sqrt(phi - sq).reshape(-1, 1)))
+
+
+def augment_xq(xq: np.ndarray) -> np.ndarray:
+    """Append a zero column to every query (mips.py:68-70)."""
+    return np.hstack((xq, np.zeros((len(xq), 1), dtype="float32")))
+
+
+def retriever_metrics(pred, counts) -> dict:
+    """Recall / reciprocal rank / average precision of a 0/1 hit matrix (pretrain.py:69-85),
+    including the reference's behaviour of scoring a rank-0 hit as reciprocal rank 0."""
+    import torch
+
+    pred = pred.float()
+    counts = counts.to(pred.device)
+    first = pred.argmax(dim=-1)
+    rr = 1.0 / first.float()
+    rr = torch.where(torch.isinf(rr), torch.zeros_like(rr), rr)
+    ranks = torch.arange(1, pred.shape[-1] + 1, device=pred.device)
+    ap = ((pred.cumsum(dim=-1) / ranks) * pred).sum(dim=-1) / counts
+    return {
+        "recall": (pred.sum(dim=-1) / counts).mean().item(),
+        "reciprocal_rank": rr.mean().item(),
+        "average_precision": ap.mean().item(),
+    }
+
+
+def inner_product(x: np.ndarray, y: np.ndarray, k: int = 1, normalize: bool = True, device: int = None):
+    """Brute-force cross-check of mips.py:552-560, run on the GPU: optional row normalisation of
+    both sides, exact top-k of x @ y.T.  Scores are descending; values are the canonical scores of
+    the bf16-rounded operands."""
+    import torch
+
+    assert len(x.shape) == len(y.shape) == 2
+    dev = f"cuda:{_lib.require_gpu(device)}"
+    xd = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+    yd = torch.as_tensor(np.ascontiguousarray(y, dtype=np.float32)).to(dev)
+    if normalize:
+        l2_normalize_(xd)
+        l2_normalize_(yd)
+    ix = MipsIndex(y.shape[1], metric=METRIC_INNER_PRODUCT, device=device)
+    ix.add(yd)
+    s, i = ix.search(xd, k)
+    return s.cpu().numpy(), i.cpu().numpy()
+
+
+# --------------------------------------------------------------------------- the facade
+class _IndexHolder:
+    """`embeddings.get_index(name).faiss_index` shim (mips.py:343-345, 383)."""
+
+    def __init__(self, index):
+        self.faiss_index = index
+
+
+class KnowledgeBase:
+    """The few Dataset operations the path uses on `self.embeddings`: row fetch by id
+    (`embeddings[i][text_column]`, mips.py:428, 458), get_index (mips.py:383) and len."""
+
+    def __init__(self, columns: dict, index: MipsIndex = None, index_name: str = "mips_embeddings"):
+        self.columns = columns
+        self._indexes = {index_name: _IndexHolder(index)} if index is not None else {}
+
+    def __len__(self):
+        return len(next(iter(self.columns.values()))) if self.columns else 0
+
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            return self.columns[key]
+        if isinstance(key, (int, np.integer)):
+            return {c: v[int(key)] for c, v in self.columns.items()}
+        ids = [int(i) for i in key]
+        return {c: [v[i] for i in ids] for c, v in self.columns.items()}
+
+    def get_index(self, name: str):
+        return self._indexes[name]
+
+    def add_index(self, name: str, index: MipsIndex):
+        self._indexes[name] = _IndexHolder(index)
+
+    def drop_index(self, name: str):
+        self._indexes.pop(name, None)
+
+    def get_nearest_examples_batch(self, index_name: str, queries, k: int = 10):
+        """HF Dataset.get_nearest_examples_batch as used at retriever_lightning.py:317-321:
+        returns (scores per query, examples per query as dict of columns); ids < 0 are dropped
+        like datasets/search.py does."""
+        s, i = self.get_index(index_name).faiss_index.search(np.ascontiguousarray(queries, dtype=np.float32), k)
+        scores, examples = [], []
+        for row_s, row_i in zip(s, i):
+            keep = row_i >= 0
+            scores.append(row_s[keep])
+            examples.append(self[row_i[keep]])
+        return scores, examples
+
+
+class Mips:
+    def __init__(self, args: MipsArgs = None, data: dict = None) -> None:
+        self.args = args if args is not None else MipsArgs()
+
+        self.tmp_folder = Path(self.args.mips_tmp_folder)
+        self.embeddings_tmp_folder = self.tmp_folder / "embeddings_tmp"
+        self.mips_folder = self.tmp_folder / "mips"
+        self.index_file = self.mips_folder / "index"          # directory (meta.json + rows.bf16)
+        self.max_norm_file = self.mips_folder / "max_norm.pkl"
+        self.embeddings_folder = self.mips_folder / "embeddings"
+
+        # knowledge-base columns (text_column / index_column lists); the reference loads them from
+        # Multi-XScience / arXiv (mips.py:167-185), which needs the hub -> supplied by the caller
+        self.data = data
+        if data is not None and isinstance(self.args.mips_db_max_size, int):
+            self.data = {c: v[: self.args.mips_db_max_size] for c, v in data.items()}
+
+        self.string_factory = self.args.mips_string_factory
+        self.train_size = self.args.mips_train_size
+        self.metric_type = self.args.mips_metric_type
+        self.normalize = self.args.mips_normalize
+
+        self.max_norm = None
+        self.phi = None
+        self.rebuilt_steps = [0]
+        self.text_column = "mips_column"
+        self.index_column = "aid"
+        self.index_name = "mips_embeddings"
+        self.embeddings: KnowledgeBase = None
+        self.embeddings_column = "embeddings"
+        self.scale_topk = 16
+
+    # ------------------------------------------------------------------ index build (mips.py:290-345)
+    def init_embeddings_folder(self) -> None:
+        shutil.rmtree(self.embeddings_folder, ignore_errors=True)
+        self.embeddings_folder.mkdir(parents=True, exist_ok=True)
+
+    def build_index(self, embeddings=None) -> None:
+        """max_norm (mips.py:298-304) -> optional document normalisation for IP (:306-314) ->
+        [L2: phi, mips.py:316-324; the augmentation column is implicit in the backend] ->
+        Flat index (:333-340).  `embeddings`: float32 [N, d] NumPy array or torch tensor (the CLS
+        vectors the reference collects from per-rank shards, mips.py:292-295)."""
+        import torch
+
+        if self.string_factory not in (None, "Flat"):
+            raise NotImplementedError(
+                f"mips_string_factory={self.string_factory!r}: only the exact 'Flat' index is implemented")
+        if embeddings is None:
+            raise ValueError("build_index needs the [N, d] embedding matrix")
+        dev = f"cuda:{_lib.require_gpu(self.args.mips_device)}"
+        x = torch.as_tensor(embeddings)
+        if isinstance(self.args.mips_db_max_size, int):
+            x = x[: self.args.mips_db_max_size]
+        x = x.to(dev, dtype=torch.float32).contiguous()
+        if isinstance(embeddings, torch.Tensor) and x.data_ptr() == embeddings.data_ptr():
+            x = x.clone()  # normalisation below is in place; never touch the caller's tensor
+
+        self.max_norm = float(np.sqrt(rows_max_sumsq(x)))
+        if self.normalize and self.metric_type == METRIC_INNER_PRODUCT:
+            l2_normalize_(x)
+
+        index = MipsIndex(x.shape[1], metric=self.metric_type, dtype=self.args.mips_index_dtype,
+                          device=self.args.mips_device)
+        index.reserve(x.shape[0])
+        index.add(x)
+        if self.metric_type == METRIC_L2:
+            self.phi = index.phi()
+        if isinstance(self.args.mips_nprobe, int):
+            index.nprobe = self.args.mips_nprobe
+        cols = dict(self.data) if self.data is not None else {}
+        self.embeddings = KnowledgeBase(cols, index, self.index_name)
+
+    # ------------------------------------------------------------------ query side
+    def l2_normalization(self, x: np.ndarray) -> np.ndarray:
+        """mips.py:521-525 (faiss.normalize_L2: in place, rows of norm 0 untouched)."""
+        if not x.flags.c_contiguous:
+            x = np.asarray(x, order="C")
+        nr = np.einsum("ij,ij->i", x, x, dtype=np.float32)
+        scale = np.ones_like(nr)
+        np.divide(np.float32(1.0), np.sqrt(nr), out=scale, where=nr > 0)
+        x *= scale[:, None]
+        return x
+
+    def _prepare_query(self, query: np.ndarray) -> np.ndarray:
+        """mips.py:368-375."""
+        if self.normalize and self.metric_type == METRIC_INNER_PRODUCT:
+            query = self.l2_normalization(query)
+        if self.metric_type == METRIC_L2:
+            query = augment_xq(query)
+        if not query.flags.c_contiguous:
+            query = np.asarray(query, order="C")
+        return query.astype(np.float32)
+
+    def _index(self) -> MipsIndex:
+        if self.embeddings is None:
+            raise RuntimeError("Mips: no index (call build_index() or load() first)")
+        return self.embeddings.get_index(self.index_name).faiss_index
+
+    def search(self, queries: np.ndarray, ignore_indexes: list = None, k: int = 10):
+        """mips.py:382-400: k (or k+1 when filtering) nearest rows; with ignore_indexes the hit
+        equal to ignore_indexes[j] is dropped per query and the rest cut to k (lists of lists)."""
+        index = self._index()
+        q = np.asarray(queries)
+        if self.metric_type == METRIC_L2 and q.shape[1] == index.d + 1:
+            q = q[:, :-1]  # the augmentation column of augment_xq is identically zero
+        scores, indices = index.search(q, k + 1 if ignore_indexes is not None else k)
+        if ignore_indexes is not None:
+            out_s, out_i = [], []
+            for j in range(len(indices)):
+                banned = int(ignore_indexes[j])
+                keep = [t for t in range(len(indices[j])) if indices[j][t] != banned][:k]
+                out_s.append([scores[j][t] for t in keep])
+                out_i.append([indices[j][t] for t in keep])
+            scores, indices = out_s, out_i
+        return scores, indices
+
+    def np_search(self, x, k: int = 2) -> tuple:
+        """mips.py:527-529: exhaustive cross-check over the stored embeddings."""
+        index = self._index()
+        q = np.array(x, dtype=np.float32, copy=True)
+        if self.normalize:
+            q = self.l2_normalization(q)
+        return index.search(q, k)
+
+    # ------------------------------------------------------------------ forward (mips.py:402-463)
+    def forward(self, queries: np.ndarray, aid: list = None, aid_counts=None, target_str: list = None,
+                input_str: list = None, ignore_indexes: list = None, k: int = 10) -> MipsModelOutput:
+        a = self.args
+        indices = None
+        if a.memory_forcing == "target_only" and a.multi_x_science_dataset_mode == "original":
+            flat_texts = target_str
+            k = 1
+            scores = None
+            examples = [target_str]
+        else:
+            queries = self._prepare_query(query=queries)
+            scores, indices = self.search(queries=queries, ignore_indexes=ignore_indexes, k=k)
+            examples = [self.embeddings[[i for i in row if i >= 0]][self.text_column] for row in indices]
+
+            if (a.memory_forcing == "target_in" and a.multi_x_science_dataset_mode == "original"
+                    and a.copy_forcing > random() and isinstance(target_str, list)):
+                flat_texts = [t for i, df in enumerate(examples) for t in ([target_str[i]] + df)]
+                k += 1
+            elif a.multi_x_science_dataset_mode == "dual" and input_str is not None:
+                input_list = (i.split(a.doc_sep)[:k] for i in input_str)
+                flat_texts = [j for e, i in zip(examples, input_list) for j in i + e[: (k - len(i))]]
+            else:
+                flat_texts = [t for df in examples for t in df]
+
+        metrics = None
+        if aid is not None and a.log_retriever_metrics and indices is not None:
+            import torch
+
+            full = [self.embeddings[[i for i in row if i >= 0]] for row in indices]
+            pred = torch.tensor([[b == x for x in e[self.index_column]] for e, b in zip(full, aid)]).float()
+            metrics = retriever_metrics(pred, torch.as_tensor(aid_counts).cpu())
+
+        return MipsModelOutput(scores=scores, metrics=metrics, examples=examples, query_cls=queries,
+                               indices=indices, flat_texts=flat_texts)
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------ persistence (mips.py:531-549)
+    def save(self) -> None:
+        shutil.rmtree(self.mips_folder, ignore_errors=True)
+        self.mips_folder.mkdir(parents=True, exist_ok=True)
+        self._index().save(str(self.index_file), extra={"phi": self.phi, "normalize": bool(self.normalize)})
+        self.embeddings_folder.mkdir(parents=True, exist_ok=True)
+        with open(self.embeddings_folder / "columns.json", "w") as f:
+            json.dump(self.embeddings.columns, f)
+        with open(self.max_norm_file, "wb") as f:
+            pickle.dump(self.max_norm, f)
+        self.embeddings = None
+        shutil.rmtree(self.embeddings_tmp_folder, ignore_errors=True)
+
+    def load(self) -> None:
+        index = MipsIndex.load(str(self.index_file), device=self.args.mips_device)
+        with open(self.embeddings_folder / "columns.json") as f:
+            cols = json.load(f)
+        self.embeddings = KnowledgeBase(cols, index, self.index_name)
+        self.phi = index.meta.get("phi")
+        with open(self.max_norm_file, "rb") as f:
+            self.max_norm = pickle.load(f)

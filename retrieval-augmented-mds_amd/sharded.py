@@ -1,0 +1,125 @@
+"""Row-sharded search over the GPUs of one node.
+
+The reference replicates the whole FAISS index on every rank (lightning_model.py:180,
+mips.py:545-549).  Here rank r of G keeps rows [r*ceil(N/G), min(N, (r+1)*ceil(N/G))) in its own
+HBM, every rank scores ALL queries against its shard with the fused HIP kernel, and ONE collective
+-- an all-gather (RCCL over xGMI when the backend is "nccl") of the packed per-rank top-k -- is
+followed by a replicated k-way merge, identical on every rank.  No other data-path collective.
+
+The all-gather payload is one int64 tensor [nq, k, 2] per rank (float32 score bits, global row id):
+4096 x 5 x 16 B = 320 KiB at the headline config -- latency bound on xGMI.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+
+def shard_bounds(n: int, world: int, rank: int):
+    """Contiguous row partition, ceil(N/G) rows per rank (same contiguous-chunk idea as the
+    reference's encode sharding, sotasum/mips.py:227-229)."""
+    per = -(-int(n) // int(world))
+    lo = min(int(n), rank * per)
+    hi = min(int(n), (rank + 1) * per)
+    return lo, hi
+
+
+def pack_topk(scores, idx):
+    """(float32 [nq,k], int64 [nq,k]) torch tensors -> int64 [nq,k,2]."""
+    import torch
+
+    bits = scores.contiguous().view(torch.int32).to(torch.int64)
+    return torch.stack((bits, idx.to(torch.int64)), dim=-1).contiguous()
+
+
+def unpack_gathered(gathered, world: int):
+    """int64 [world, nq, k, 2] -> (float32 [nq, world*k], int64 [nq, world*k]), shard-major rows."""
+    import torch
+
+    nq, k = gathered.shape[1], gathered.shape[2]
+    g = gathered.permute(1, 0, 2, 3).reshape(nq, world * k, 2)
+    s = g[..., 0].to(torch.int32).contiguous().view(torch.float32)
+    return s, g[..., 1].contiguous()
+
+
+class ShardedMipsIndex:
+    """One logical exact index, row-sharded across the ranks of a torch.distributed group.
+
+    local_search(q, k, idx_offset) and merge(cand_s, cand_i, parts, k, metric) default to the HIP
+    path (MipsIndex.search / mips_merge_topk).  They are injectable so that the partition + pack +
+    all-gather + unpack plumbing can be exercised with the gloo backend on CPU-only machines, where
+    tests substitute the CPU oracle for the two device steps.
+    """
+
+    def __init__(self, d: int, metric: int = _lib.METRIC_IP, dtype: str = "bf16", group=None, device=None,
+                 local_search=None, merge=None):
+        import torch.distributed as dist
+
+        self.d = int(d)
+        self.metric_type = int(metric)
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.ntotal_global = 0
+        self.lo = self.hi = 0
+        self.local = None
+        if local_search is None:
+            from .index import MipsIndex
+
+            self.local = MipsIndex(d, metric=metric, dtype=dtype, device=device)
+            local_search = self.local.search
+        if merge is None:
+            from .index import merge_topk as merge
+        self._local_search = local_search
+        self._merge = merge
+
+    # ------------------------------------------------------------------ building
+    def set_global_size(self, n: int):
+        self.ntotal_global = int(n)
+        self.lo, self.hi = shard_bounds(n, self.world, self.rank)
+        return self.lo, self.hi
+
+    def add_global(self, x) -> None:
+        """Every rank sees the full [N, d] array (NumPy / memmap / torch) and keeps its own rows."""
+        lo, hi = self.set_global_size(len(x))
+        if self.local is not None and hi > lo:
+            self.local.reserve(hi - lo)
+            self.local.add(x[lo:hi])
+
+    def add_synthetic_global(self, n: int, seed: int, kind: int) -> None:
+        lo, hi = self.set_global_size(n)
+        if hi > lo:
+            self.local.reserve(hi - lo)
+            self.local.add_synthetic(hi - lo, row0=lo, seed=seed, kind=kind)
+
+    @property
+    def ntotal(self) -> int:
+        return self.ntotal_global
+
+    # ------------------------------------------------------------------ search
+    def search(self, q, k: int):
+        """Replicated queries in, global top-k out (same on every rank)."""
+        import torch
+        import torch.distributed as dist
+
+        s, i = self._local_search(q, k, self.lo)
+        if self.world == 1:
+            return s, i
+        as_numpy = not isinstance(s, torch.Tensor)
+        if as_numpy:
+            s, i = torch.from_numpy(np.ascontiguousarray(s)), torch.from_numpy(np.ascontiguousarray(i))
+        backend = dist.get_backend(self.group)
+        if backend == "nccl" and not s.is_cuda:
+            dev = f"cuda:{self.local.device}" if self.local is not None else "cuda"
+            s, i = s.to(dev), i.to(dev)
+        packed = pack_topk(s, i)
+        nq = packed.shape[0]
+        # rank-major concatenation along dim 0 (the layout both RCCL and gloo accept)
+        gathered = torch.empty((self.world * nq,) + tuple(packed.shape[1:]), dtype=torch.int64, device=packed.device)
+        dist.all_gather_into_tensor(gathered, packed, group=self.group)  # the ONE collective of the path
+        cs, ci = unpack_gathered(gathered.view((self.world, nq) + tuple(packed.shape[1:])), self.world)
+        out_s, out_i = self._merge(cs, ci, self.world, k, self.metric_type)
+        if as_numpy:
+            return out_s.cpu().numpy(), out_i.cpu().numpy()
+        return out_s, out_i

@@ -1,0 +1,326 @@
+"""GPU parity tests (MI355X): the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs and against the golden vectors of the real reference.  Bar: indices AND scores
+bit-exact against the oracle's canonical definition (integer/index work: exact; the scores are
+float32 casts of an exactly defined fp64 sum, so they are compared bit for bit as well); against
+the reference's own fp32 scores the tolerance is 1e-3 relative (BASELINE.json north star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import retrieval_augmented_mds_amd as ram
+from oracle import mips_oracle as orc
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _index(x, metric=0):
+    ix = ram.MipsIndex(x.shape[1], metric=metric)
+    ix.add(x)
+    return ix
+
+
+def _check(ix, q, x, k, metric=0, brute=False, idx_offset=0):
+    s, i = ix.search(q, k, idx_offset) if idx_offset else ix.search(q, k)
+    fn = orc.search_exact_bruteforce if brute else orc.search_exact
+    es, ei = fn(q, x, k, metric=metric, idx_offset=idx_offset)
+    assert s.dtype == np.float32 and i.dtype == np.int64 and s.shape == (len(q), k)
+    assert np.array_equal(i, ei), f"indices differ in {(i != ei).any(axis=1).sum()} of {len(q)} rows"
+    assert np.array_equal(s, es), f"scores differ, max abs {np.abs(s - es).max()}"
+    return s, i
+
+
+# ------------------------------------------------------------------ generators, conversion
+@pytest.mark.parametrize("kind", [synth.KIND_LATTICE, synth.KIND_GAUSS, synth.KIND_LATTICE_FP8])
+def test_device_generator_matches_host(kind):
+    for d, row0, n in ((768, 0, 300), (64, 12345, 130), (1024, 1 << 33, 17)):
+        ref = synth.generate(0xD0C5, row0, n, d, kind)
+        got = ram.synth_fill(n, d, row0, 0xD0C5, kind, dtype="f32").cpu().numpy()
+        assert np.array_equal(got, ref)
+        got16 = ram.synth_fill(n, d, row0, 0xD0C5, kind, dtype="bf16").float().cpu().numpy()
+        assert np.array_equal(got16, ref)
+    ix = ram.MipsIndex(768)
+    ix.add_synthetic(257, row0=1000, seed=77, kind=kind)
+    assert ix.ntotal == 257
+    assert np.array_equal(synth.bf16_bits_to_f32(ix.rows_bf16()), synth.generate(77, 1000, 257, 768, kind))
+
+
+def test_add_rounds_to_bf16_and_grows():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1000, 100)).astype(np.float32)
+    ix = ram.MipsIndex(100)
+    ix.add(x[:10])
+    ix.add(torch.from_numpy(x[10:300]))                       # host torch
+    ix.add(torch.from_numpy(x[300:700]).cuda())               # device f32
+    ix.add(torch.from_numpy(x[700:900]).cuda().bfloat16())    # device bf16
+    ix.add(synth.bf16_bits(synth.round_to_bf16(x[900:])))     # raw bf16 bits from the host
+    assert ix.ntotal == 1000 and ix.d == 100 and len(ix) == 1000
+    assert np.array_equal(ix.rows_bf16(), synth.bf16_bits(synth.round_to_bf16(x)))
+    assert np.array_equal(ix.rows_bf16(123, 7), synth.bf16_bits(synth.round_to_bf16(x[123:130])))
+    ix.reset()
+    assert ix.ntotal == 0
+    ix.add(x[:5])
+    assert np.array_equal(ix.rows_bf16(), synth.bf16_bits(synth.round_to_bf16(x[:5])))
+    with pytest.raises(ValueError):
+        ix.add(np.zeros((3, 99), np.float32))
+
+
+# ------------------------------------------------------------------ search parity
+def test_lattice_small_bit_exact_with_ties():
+    x = synth.generate(5, 0, 1000, 64, synth.KIND_LATTICE)
+    q = synth.generate(6, 0, 7, 64, synth.KIND_LATTICE)
+    x[10] = x[700]
+    x[333] = x[700]              # exact duplicates: ties must resolve to the lowest index
+    q[0] = x[700]
+    ix = _index(x)
+    s, i = _check(ix, q, x, 5, brute=True)
+    assert list(i[0][:3]) == [10, 333, 700] and s[0][0] == s[0][1] == s[0][2]
+
+
+def test_all_equal_scores_return_lowest_indices():
+    x = np.ones((500, 64), dtype=np.float32)
+    q = np.ones((3, 64), dtype=np.float32)
+    s, i = _index(x).search(q, 5)
+    assert np.array_equal(i, np.tile(np.arange(5), (3, 1))) and (s == 64.0).all()
+
+
+def test_cfg1_matches_reference_golden(golden_dir):
+    """BASELINE config 1: 10 000 x 768 index, 8 queries, k = 5 -- the indices the REAL reference
+    inner_product returned (tests/golden), and its fp32 scores within 1e-3 relative."""
+    g = np.load(os.path.join(golden_dir, "g1_g2_inner_product.npz"))
+    x = synth.generate(int(g["seed_docs"]), 0, int(g["n"]), int(g["d"]), int(g["kind"]))
+    q = g["queries"]
+    ix = _index(x)
+    s, i = _check(ix, q, x, int(g["k"]))
+    assert np.array_equal(i, g["indices_raw"])
+    np.testing.assert_allclose(s, g["scores_raw"], rtol=1e-3)
+    # the product's brute-force helper (mips.py:552-560 surface), un-normalised
+    s2, i2 = ram.inner_product(q, x, k=5, normalize=False)
+    assert np.array_equal(i2, g["indices_raw"]) and np.array_equal(s2, s)
+
+
+@pytest.mark.parametrize("n,nq,d,k", [(100003, 257, 768, 5), (4099, 129, 1024, 10), (777, 5, 100, 1),
+                                       (20000, 130, 769, 16), (131, 3, 64, 13), (128, 128, 64, 6)])
+def test_ragged_shapes_gauss(n, nq, d, k):
+    x = synth.generate(21, 0, n, d, synth.KIND_GAUSS)
+    q = synth.generate(22, 0, nq, d, synth.KIND_GAUSS)
+    _check(_index(x), q, x, k)
+
+
+@pytest.mark.parametrize("k", [1, 5, 6, 13, 14, 29])
+def test_k_variants_lattice(k):
+    x = synth.generate(31, 0, 5000, 128, synth.KIND_LATTICE)
+    q = synth.generate(32, 0, 33, 128, synth.KIND_LATTICE)
+    _check(_index(x), q, x, k, brute=True)
+
+
+def test_k_limits_and_degenerate_calls():
+    x = synth.generate(1, 0, 3, 64, synth.KIND_LATTICE)
+    q = synth.generate(2, 0, 2, 64, synth.KIND_LATTICE)
+    ix = _index(x)
+    s, i = _check(ix, q, x, 5, brute=True)                    # k > ntotal: padded
+    assert (i[:, 3:] == -1).all() and np.isneginf(s[:, 3:]).all()
+    with pytest.raises(NotImplementedError):
+        ix.search(q, ram.MAX_K + 1)
+    s, i = ix.search(np.zeros((0, 64), np.float32), 4)
+    assert s.shape == (0, 4) and i.shape == (0, 4)
+    s, i = ix.search(q, 0)
+    assert s.shape == (2, 0)
+    empty = ram.MipsIndex(64)
+    s, i = empty.search(q, 3)
+    assert (i == -1).all() and np.isneginf(s).all()
+    empty_l2 = ram.MipsIndex(64, metric=ram.METRIC_L2)
+    s, i = empty_l2.search(q, 3)
+    assert (i == -1).all() and np.isposinf(s).all()
+
+
+def test_l2_metric_matches_oracle_and_augmented_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g5_ip_equals_aug_l2.npz"))
+    x = synth.generate(int(g["seed_b"]), 0, int(g["n"]), int(g["d"]), int(g["kind"]))
+    q = synth.generate(int(g["seed_q"]), 0, int(g["nq"]), int(g["d"]), int(g["kind"]))
+    ix = _index(x, metric=ram.METRIC_L2)
+    s, i = _check(ix, q, x, int(g["k"]), metric=orc.METRIC_L2)
+    assert np.array_equal(i, g["l2_indices"]) and np.array_equal(i, g["ip_indices"])
+    np.testing.assert_allclose(s, g["l2_dist"], rtol=1e-3)     # vs brute force on the reference's augmented vectors
+    assert (np.diff(s, axis=1) >= 0).all()
+    assert ix.phi() == pytest.approx(float(g["phi"]), rel=1e-6)
+    # padding in L2 mode
+    small = _index(x[:2], metric=ram.METRIC_L2)
+    s, i = small.search(q, 4)
+    assert (i[:, 2:] == -1).all() and np.isposinf(s[:, 2:]).all()
+
+
+def test_device_tensors_in_and_out():
+    x = synth.generate(41, 0, 3000, 768, synth.KIND_GAUSS)
+    q = synth.generate(42, 0, 70, 768, synth.KIND_GAUSS)
+    ix = _index(torch.from_numpy(x).cuda())
+    es, ei = orc.search_exact(q, x, 5)
+    for qt in (torch.from_numpy(q).cuda(), torch.from_numpy(q).cuda().bfloat16()):
+        s, i = ix.search(qt, 5)
+        assert s.is_cuda and i.is_cuda and s.dtype == torch.float32 and i.dtype == torch.int64
+        assert np.array_equal(i.cpu().numpy(), ei) and np.array_equal(s.cpu().numpy(), es)
+    s, i = ix.search(torch.from_numpy(q), 5)                   # host torch -> numpy out
+    assert np.array_equal(i, ei)
+
+
+def test_non_bf16_inputs_are_rounded_like_the_oracle():
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((5000, 96)).astype(np.float32)
+    q = rng.standard_normal((9, 96)).astype(np.float32)
+    _check(_index(x), synth.round_to_bf16(q), synth.round_to_bf16(x), 5)
+    s, i = _index(x).search(q, 5)
+    es, ei = orc.search_exact(synth.round_to_bf16(q), synth.round_to_bf16(x), 5)
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+
+
+def test_idx_offset_and_shard_merge_equal_full_index():
+    n, d, k = 30011, 256, 5
+    x = synth.generate(51, 0, n, d, synth.KIND_LATTICE)
+    q = synth.generate(52, 0, 140, d, synth.KIND_LATTICE)
+    full = _index(x)
+    fs, fi = _check(full, q, x, k)
+    qd = torch.from_numpy(q).cuda()
+    for world in (2, 3, 8):
+        ps, pi = [], []
+        for r in range(world):
+            lo, hi = ram.shard_bounds(n, world, r)
+            s, i = _index(x[lo:hi]).search(qd, k, lo)
+            ps.append(s)
+            pi.append(i)
+        cs, ci = torch.cat(ps, dim=1), torch.cat(pi, dim=1)
+        ms, mi = ram.merge_topk(cs, ci, world, k)
+        assert np.array_equal(mi.cpu().numpy(), fi) and np.array_equal(ms.cpu().numpy(), fs)
+        os_, oi_ = orc.merge_topk([p.cpu().numpy() for p in ps], [p.cpu().numpy() for p in pi], k)
+        assert np.array_equal(oi_, fi) and np.array_equal(os_, fs)
+
+
+def test_merge_topk_kernel_padding_and_l2():
+    s = torch.tensor([[5., 4., float("-inf"), 5., 1., float("-inf")]]).cuda()
+    i = torch.tensor([[9, 3, -1, 2, 7, -1]]).cuda()
+    ms, mi = ram.merge_topk(s, i, 2, 3)
+    assert mi.cpu().tolist() == [[2, 9, 3]] and ms.cpu().tolist() == [[5., 5., 4.]]
+    ms, mi = ram.merge_topk(s, i, 2, 6)
+    assert mi.cpu().tolist() == [[2, 9, 3, 7, -1, -1]]
+    s2 = torch.tensor([[1., 2., float("inf"), 0.5, 2., float("inf")]]).cuda()
+    ms, mi = ram.merge_topk(s2, i, 2, 3, metric=ram.METRIC_L2)
+    assert mi.cpu().tolist() == [[2, 9, 3]] and ms.cpu().tolist() == [[0.5, 1., 2.]]
+
+
+# ------------------------------------------------------------------ facade on the device
+def test_l2_normalize_kernel_and_max_norm():
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((513, 768)).astype(np.float32) * 3
+    x[17] = 0
+    xd = torch.from_numpy(x).cuda()
+    assert ram.rows_max_sumsq(xd) == pytest.approx(float((x.astype(np.float64) ** 2).sum(1).max()), rel=1e-12)
+    ram.l2_normalize_(xd)
+    ref = orc.l2_normalization(x.copy())
+    np.testing.assert_allclose(xd.cpu().numpy(), ref, rtol=3e-6, atol=1e-8)   # fp32 sum order differs
+    assert (xd[17] == 0).all()
+
+
+@pytest.mark.parametrize("metric,normalize", [(0, True), (0, False), (1, True)])
+def test_mips_facade_end_to_end(tmp_path, metric, normalize):
+    n, d, k = 10000, 768, 5
+    rng = np.random.default_rng(11)
+    emb = (synth.generate(61, 0, n, d, synth.KIND_GAUSS) * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
+    qs = synth.generate(62, 0, 8, d, synth.KIND_GAUSS)
+    data = {"mips_column": [f"text {i}" for i in range(n)], "aid": [f"a{i}" for i in range(n)]}
+    args = ram.MipsArgs(mips_topk=k, mips_metric_type=metric, mips_normalize=normalize,
+                        mips_tmp_folder=str(tmp_path), log_retriever_metrics=True)
+    m = ram.Mips(args, data=data)
+    m.build_index(emb)
+    assert m.max_norm == pytest.approx(float(np.linalg.norm(emb.astype(np.float64), axis=1).max()), rel=1e-6)
+    index = m.embeddings.get_index(m.index_name).faiss_index
+    stored = synth.bf16_bits_to_f32(index.rows_bf16())          # what the device actually holds
+    if normalize and metric == 0:
+        np.testing.assert_allclose(np.linalg.norm(stored, axis=1), 1.0, atol=2e-2)
+    pq = m._prepare_query(qs.copy())
+    assert np.array_equal(pq, orc.prepare_query(qs.copy(), normalize, metric))
+    q_for_oracle = synth.round_to_bf16(pq[:, :d])
+    es, ei = orc.search_exact(q_for_oracle, stored, k, metric=metric)
+    s, i = m.search(pq, k=k)
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+    # ignore_indexes: mips.py:388-398
+    ignore = [int(ei[j][0]) for j in range(8)]
+    s2, i2 = m.search(pq, ignore_indexes=ignore, k=k)
+    es2, ei2 = orc.mips_search(lambda qq, kk: orc.search_exact(q_for_oracle, stored, kk, metric=metric), pq, ignore, k)
+    assert [list(map(int, r)) for r in i2] == [list(map(int, r)) for r in ei2]
+    assert all(ignore[j] not in i2[j] and len(i2[j]) == k for j in range(8))
+    # forward + metrics
+    out = m.forward(qs.copy(), aid=[f"a{int(ei[j][1])}" for j in range(8)], aid_counts=torch.ones(8), k=k)
+    assert out.examples[3][0] == f"text {int(ei[3][0])}" and len(out.flat_texts) == 8 * k
+    assert out.metrics["recall"] == pytest.approx(1.0) and out.metrics["reciprocal_rank"] == pytest.approx(1.0)
+    # save / load round trip (mips.py:531-549)
+    m.save()
+    assert m.embeddings is None
+    m2 = ram.Mips(args)
+    m2.load()
+    assert m2.max_norm == m.max_norm
+    s3, i3 = m2.search(pq, k=k)
+    assert np.array_equal(i3, ei) and np.array_equal(s3, es)
+    assert m2.embeddings[int(ei[0][0])]["mips_column"] == f"text {int(ei[0][0])}"
+    # full-KB eval surface (retriever_lightning.py:317-321)
+    sc, ex = m2.embeddings.get_nearest_examples_batch(m2.index_name, pq[:, :d], k=k)
+    assert ex[0]["aid"] == [f"a{int(t)}" for t in ei[0]]
+
+
+def test_index_save_load_row_range(tmp_path):
+    x = synth.generate(71, 0, 5000, 128, synth.KIND_GAUSS)
+    q = synth.generate(72, 0, 6, 128, synth.KIND_GAUSS)
+    ix = _index(x)
+    ix.save(str(tmp_path / "ix"))
+    part = ram.MipsIndex.load(str(tmp_path / "ix"), row_range=(1000, 3000))
+    assert part.ntotal == 2000
+    s, i = part.search(q, 5, 1000)
+    es, ei = orc.search_exact(q, x[1000:3000], 5, idx_offset=1000)
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+
+
+# ------------------------------------------------------------------ BASELINE config 2 at full size
+def test_cfg2_full_size_properties_and_oracle_subset():
+    """2^20 x 768 bf16 index, Q = 4096, k = 5 (the bench workload).  Oracle on a 48-query subset;
+    size-independent properties on all 4096: sortedness with ties by index, returned scores equal
+    the canonical re-score of (query, returned doc), a 2-shard split + merge reproduces the result,
+    planted duplicates of documents are retrieved as their own nearest neighbour."""
+    n, d, nq, k = 1 << 20, 768, 4096, 5
+    ix = ram.MipsIndex(d)
+    ix.add_synthetic(n, row0=0, seed=synth.SEED_DOCS, kind=synth.KIND_GAUSS)
+    qd = ram.synth_fill(nq, d, 0, synth.SEED_QUERIES, synth.KIND_GAUSS, dtype="bf16")
+    plant = np.arange(0, 4096, 64)
+    rows = torch.from_numpy(synth.bf16_bits_to_f32(np.concatenate(
+        [ix.rows_bf16(int(r) * 251 + 5, 1) for r in plant]))).cuda().bfloat16()
+    qd[torch.from_numpy(plant).cuda()] = rows
+    s, i = ix.search(qd, k)
+    torch.cuda.synchronize()
+    s, i = s.cpu().numpy(), i.cpu().numpy()
+    q = qd.float().cpu().numpy()
+    assert (i >= 0).all() and (i < n).all()
+    assert ((np.diff(s, axis=1) < 0) | ((np.diff(s, axis=1) == 0) & (np.diff(i, axis=1) > 0))).all()
+    assert np.array_equal(i[plant, 0], plant * 251 + 5)
+    # canonical re-score of every returned pair, from independently regenerated rows
+    flat = np.unique(i)
+    rows = {int(r): synth.generate(synth.SEED_DOCS, int(r), 1, d, synth.KIND_GAUSS)[0] for r in flat}
+    docs = np.stack([rows[int(r)] for r in i.reshape(-1)]).reshape(nq, k, d)
+    canon = np.stack([orc.canonical_pairs(q[j:j + 1], docs[j], np.arange(k)[None, :])[0] for j in range(nq)])
+    assert np.array_equal(canon.astype(np.float32), s)
+    # oracle on a subset of queries (chunked fp64 candidates + canonical re-score)
+    sub = np.r_[0:32, plant[:16]]
+    x = np.concatenate([b for _, b in synth.generate_blocked(synth.SEED_DOCS, 0, n, d, synth.KIND_GAUSS)])
+    es, ei = orc.search_exact(q[sub], x, k)
+    assert np.array_equal(i[sub], ei) and np.array_equal(s[sub], es)
+    del x
+    # shard + merge == unsharded
+    ps, pi = [], []
+    for r in range(2):
+        lo, hi = ram.shard_bounds(n, 2, r)
+        part = ram.MipsIndex(d)
+        part.add_synthetic(hi - lo, row0=lo, seed=synth.SEED_DOCS, kind=synth.KIND_GAUSS)
+        a, b = part.search(qd, k, lo)
+        ps.append(a)
+        pi.append(b)
+        del part
+    ms, mi = ram.merge_topk(torch.cat(ps, 1), torch.cat(pi, 1), 2, k)
+    assert np.array_equal(mi.cpu().numpy(), i) and np.array_equal(ms.cpu().numpy(), s)

@@ -1,0 +1,259 @@
+"""CPU tests of the product's host side: the C-ABI library builds, loads and exports every symbol
+include/mips_hip.h declares (no compute without a GPU); the Mips facade's host logic against the
+oracle (with the oracle standing in for the device index); sharding arithmetic and the packed
+all-gather on a 2-rank gloo group."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import retrieval_augmented_mds_amd as ram
+from oracle import mips_oracle as orc
+from oracle import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_loads_and_exports_header_symbols():
+    header = open(os.path.join(ROOT, "include", "mips_hip.h")).read()
+    declared = set(re.findall(r"\b(mips_[a-z0-9_]+)\s*\(", header))
+    declared.discard("mips_hip")
+    assert declared, "no declarations parsed"
+    lib = ram._lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in mips_hip.h but not exported"
+    assert set(ram._lib.EXPORTS) == declared
+    assert lib.mips_abi_version() == ram._lib.ABI_VERSION == 1
+    assert int(re.search(r"#define MIPS_MAX_K (\d+)", header).group(1)) == ram.MAX_K
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_fails_loudly_without_gpu():
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ram.MipsIndex(16)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ram.inner_product(np.zeros((1, 8), np.float32), np.zeros((2, 8), np.float32), 1)
+    m = ram.Mips(ram.MipsArgs())
+    with pytest.raises(RuntimeError):
+        m.build_index(np.zeros((4, 8), np.float32))
+    with pytest.raises(RuntimeError, match="no index"):
+        m.search(np.zeros((1, 8), np.float32), k=1)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "retrieval-augmented-mds_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, re.M), f
+                assert "mips_oracle" not in text, f
+
+
+class OracleIndex:
+    """Stands in for the device index in CPU tests: exact search on bf16-rounded data."""
+
+    def __init__(self, x, metric=0):
+        self.x = synth.round_to_bf16(np.asarray(x, dtype=np.float32))
+        self.d = self.x.shape[1]
+        self.metric = metric
+        self.calls = []
+
+    @property
+    def ntotal(self):
+        return len(self.x)
+
+    def search(self, q, k, idx_offset=0):
+        self.calls.append((np.asarray(q).shape, k))
+        q = synth.round_to_bf16(np.asarray(q, dtype=np.float32))
+        return orc.search_exact_bruteforce(q, self.x, k, metric=self.metric, idx_offset=idx_offset)
+
+
+def _facade(metric=0, normalize=True, n=300, d=32, **kw):
+    x = synth.generate(3, 0, n, d, synth.KIND_GAUSS)
+    data = {"mips_column": [f"doc {i}" for i in range(n)], "aid": [f"a{i}" for i in range(n)]}
+    m = ram.Mips(ram.MipsArgs(mips_metric_type=metric, mips_normalize=normalize, **kw), data=data)
+    m.embeddings = ram.KnowledgeBase(dict(data), OracleIndex(x, metric), m.index_name)
+    return m, x
+
+
+def test_helpers_match_oracle():
+    xb = synth.generate(7, 0, 64, 48, synth.KIND_GAUSS)
+    xq = synth.generate(8, 0, 5, 48, synth.KIND_GAUSS)
+    assert ram.get_phi(xb) == orc.get_phi(xb)
+    assert np.array_equal(ram.augment_xb(xb), orc.augment_xb(xb))
+    assert np.array_equal(ram.augment_xb(xb, phi=np.float32(99.0)), orc.augment_xb(xb, phi=np.float32(99.0)))
+    assert np.array_equal(ram.augment_xq(xq), orc.augment_xq(xq))
+    assert ram.augment_xb(xb).dtype == np.float32 and ram.augment_xq(xq).dtype == np.float32
+
+
+def test_retriever_metrics_match_goldens(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4_retriever_metrics.npz"))
+    for n in range(int(g["ncases"])):
+        out = ram.retriever_metrics(torch.tensor(g[f"pred{n}"]), torch.tensor(g[f"counts{n}"]))
+        got = np.array([out["recall"], out["reciprocal_rank"], out["average_precision"]])
+        np.testing.assert_allclose(got, g[f"out{n}"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("metric,normalize", [(0, True), (0, False), (1, True)])
+def test_prepare_query_matches_oracle(metric, normalize):
+    m, _ = _facade(metric, normalize)
+    q = synth.generate(5, 0, 6, 32, synth.KIND_GAUSS)
+    got = m._prepare_query(q.copy())
+    exp = orc.prepare_query(q.copy(), normalize, metric)
+    assert got.dtype == np.float32 and got.flags.c_contiguous and np.array_equal(got, exp)
+    got = m._prepare_query(np.asfortranarray(q.copy()))
+    assert np.array_equal(got, exp)
+
+
+def test_l2_normalization_is_in_place():
+    m, _ = _facade()
+    q = synth.generate(5, 0, 4, 32, synth.KIND_GAUSS).copy()
+    q[2] = 0
+    ref = orc.l2_normalization(q.copy())
+    out = m.l2_normalization(q)
+    assert out is q and np.array_equal(q, ref)
+
+
+def test_search_and_ignore_filter_match_oracle():
+    m, x = _facade(0, False)
+    q = synth.generate(5, 0, 6, 32, synth.KIND_GAUSS)
+    index = m.embeddings.get_index(m.index_name).faiss_index
+    s, i = m.search(q, k=4)
+    es, ei = orc.mips_search(index.search, q, None, 4)
+    assert np.array_equal(i, ei) and np.array_equal(s, es) and isinstance(s, np.ndarray)
+    # ignore: k+1 fetched, equal id dropped, cut to k, lists of lists
+    ignore = [int(ei[0][0]), 10 ** 6, int(ei[2][3]), int(ei[3][1]), -5, int(ei[5][0])]
+    index.calls.clear()
+    s, i = m.search(q, ignore_indexes=ignore, k=4)
+    assert index.calls[-1][1] == 5
+    es, ei2 = orc.mips_search(index.search, q, ignore, 4)
+    assert isinstance(i, list) and all(len(r) == 4 for r in i)
+    assert [list(map(int, r)) for r in i] == [list(map(int, r)) for r in ei2]
+    assert [list(map(float, r)) for r in s] == [list(map(float, r)) for r in es]
+    assert ignore[0] not in i[0] and ignore[2] not in i[2]
+    # tensors are accepted for ignore_indexes like in the reference
+    s2, i2 = m.search(q, ignore_indexes=torch.tensor(ignore), k=4)
+    assert [list(map(int, r)) for r in i2] == [list(map(int, r)) for r in i]
+
+
+def test_l2_mode_strips_the_augmentation_column():
+    m, x = _facade(1, True)
+    q = synth.generate(5, 0, 3, 32, synth.KIND_GAUSS)
+    pq = m._prepare_query(q.copy())
+    assert pq.shape == (3, 33)
+    s, i = m.search(pq, k=5)
+    es, ei = orc.search_exact_bruteforce(q, x, 5, metric=1)
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+    # and equals brute-force L2 on the reference's augmented vectors
+    ab, aq = orc.augment_xb(x).astype(np.float64), orc.augment_xq(q).astype(np.float64)
+    d2 = ((aq[:, None, :] - ab[None, :, :]) ** 2).sum(-1)
+    assert np.array_equal(np.argsort(d2, axis=1)[:, :5], i)
+    np.testing.assert_allclose(np.take_along_axis(d2, i, 1), s, rtol=1e-5)
+
+
+def test_forward_variants():
+    m, x = _facade(0, True, log_retriever_metrics=True)
+    q = synth.generate(5, 0, 3, 32, synth.KIND_GAUSS)
+    out = m.forward(q.copy(), k=2)
+    assert isinstance(out, ram.MipsModelOutput)
+    assert [len(e) for e in out.examples] == [2, 2, 2] and len(out.flat_texts) == 6
+    assert out.examples[0][0] == f"doc {int(out.indices[0][0])}"
+    assert np.array_equal(out.query_cls, orc.prepare_query(q.copy(), True, 0)) and out.metrics is None
+    # metrics: aid of the first hit for query 0, unknown for the others
+    hit = int(out.indices[0][1])
+    out = m(q.copy(), aid=[f"a{hit}", "zz", "zz"], aid_counts=torch.tensor([1, 1, 1]), k=2)
+    exp = orc.retriever_metrics(torch.tensor([[0., 1.], [0., 0.], [0., 0.]]), torch.tensor([1, 1, 1]))
+    assert out.metrics == pytest.approx(exp)
+    # target_only: no search at all
+    m.args.memory_forcing = "target_only"
+    out = m.forward(q.copy(), target_str=["t0", "t1", "t2"], k=2)
+    assert out.scores is None and out.examples == [["t0", "t1", "t2"]] and out.flat_texts == ["t0", "t1", "t2"]
+    # target_in with copy_forcing = 1 prepends the target
+    m.args.memory_forcing, m.args.copy_forcing = "target_in", 2.0
+    out = m.forward(q.copy(), target_str=["t0", "t1", "t2"], k=2)
+    assert len(out.flat_texts) == 9 and out.flat_texts[0] == "t0" and out.flat_texts[3] == "t1"
+    # dual mode fills up to k with retrieved texts after the input documents
+    m.args.memory_forcing, m.args.multi_x_science_dataset_mode = "no_forcing", "dual"
+    out = m.forward(q.copy(), input_str=["x <DOC_SEP> y <DOC_SEP> z", "x", "x <DOC_SEP> y"], k=2)
+    assert out.flat_texts[:2] == ["x", "y"] and out.flat_texts[2] == "x" and out.flat_texts[3] == out.examples[1][0]
+
+
+def test_build_index_rejects_non_flat_factories():
+    m = ram.Mips(ram.MipsArgs(mips_string_factory="IVF4096,Flat"))
+    with pytest.raises(NotImplementedError, match="Flat"):
+        m.build_index(np.zeros((4, 8), np.float32))
+
+
+def test_knowledge_base_nearest_examples_batch():
+    x = synth.generate(3, 0, 50, 16, synth.KIND_GAUSS)
+    kb = ram.KnowledgeBase({"mips_column": [str(i) for i in range(50)], "aid": [[i] for i in range(50)]},
+                           OracleIndex(x[:3]), "mips_cls")
+    q = synth.generate(4, 0, 2, 16, synth.KIND_GAUSS)
+    scores, examples = kb.get_nearest_examples_batch("mips_cls", q, k=5)   # k > ntotal: -1 ids dropped
+    assert [len(s) for s in scores] == [3, 3] and len(examples[0]["mips_column"]) == 3
+    assert kb[4]["mips_column"] == "4" and kb[[1, 2]]["aid"] == [[1], [2]] and len(kb) == 50
+
+
+def test_shard_bounds_cover_and_match_oracle():
+    for n in (0, 1, 7, 8, 1003, 1 << 20):
+        for w in (1, 2, 3, 4, 8):
+            spans = [ram.shard_bounds(n, w, r) for r in range(w)]
+            assert spans == [orc.shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_pack_unpack_roundtrip():
+    s = torch.tensor([[1.5, -0.0, float("-inf")], [3.25, 2.0, 1e-30]])
+    i = torch.tensor([[7, 1 << 40, -1], [0, 5, 9]])
+    p = ram.pack_topk(s, i)
+    assert p.dtype == torch.int64 and p.shape == (2, 3, 2)
+    g = torch.stack([p, p + 0])
+    us, ui = ram.unpack_gathered(g, 2)
+    assert us.shape == (2, 6) and torch.equal(us[:, :3], s) and torch.equal(us[:, 3:], s)
+    assert torch.equal(ui[:, :3], i) and torch.equal(ui[:, 3:], i)
+    assert np.signbit(us[0, 1].item())      # bit patterns survive (-0.0)
+
+
+def _gloo_worker(rank, world, port, n, nq, d, k, ret):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x = synth.generate(9, 0, n, d, synth.KIND_LATTICE)
+        q = synth.generate(10, 0, nq, d, synth.KIND_LATTICE)
+        lo, hi = ram.shard_bounds(n, world, rank)
+
+        def local_search(qq, kk, off):      # oracle stands in for the device search of this shard
+            assert off == lo
+            return orc.search_exact_bruteforce(qq, x[lo:hi], kk, idx_offset=off)
+
+        def merge(cs, ci, parts, kk, metric):  # oracle stands in for mips_merge_topk
+            assert parts == world and cs.shape == (nq, world * kk)
+            s, i = orc.merge_topk([cs.numpy()], [ci.numpy()], kk, metric)
+            return torch.from_numpy(s), torch.from_numpy(i)
+
+        ix = ram.ShardedMipsIndex(d, local_search=local_search, merge=merge)
+        assert (ix.rank, ix.world) == (rank, world)
+        ix.set_global_size(n)
+        s, i = ix.search(q, k)
+        es, ei = orc.search_exact_bruteforce(q, x, k)
+        ret[rank] = bool(np.array_equal(i, ei) and np.array_equal(s, es))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 1003), (2, 3)])
+def test_sharded_search_two_ranks_gloo(world, n):
+    import torch.multiprocessing as mp
+
+    port = 29500 + (os.getpid() % 2000) + n % 7
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gloo_worker, args=(world, port, n, 5, 64, 4, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
