@@ -148,10 +148,11 @@ int mips_l2_normalize(float* x_device, int64_t n, int64_t d, int device, void* h
 int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out_host, int device,
                         void* hip_stream);
 
-/* Timing hook used by bench.py: duration in milliseconds of the fused scan kernel of the
- * most recent mips_search on this index, measured with HIP events on the search stream
- * (valid after that stream was synchronised; < 0 if unavailable). */
-int mips_last_scan_ms(mips_index_t* index, float* out_ms);
+/* Timing hook used by bench.py: every mips_search records a HIP event pair around its fused scan
+ * kernel on the search stream (a ring of 128 pairs).  Returns the summed duration in ms and the
+ * number of scan launches recorded since the last reset (at most 128); the stream must have been
+ * synchronised.  reset != 0 starts a new measurement window. */
+int mips_scan_timing(mips_index_t* index, float* out_sum_ms, int* out_count, int reset);
 
 #ifdef __cplusplus
 }

@@ -166,10 +166,20 @@ class MipsIndex:
         del keep
         return D, I
 
+    def scan_timing(self, reset: bool = False):
+        """(summed ms, launches) of the fused scan kernel since the last reset, from HIP events on
+        the search stream (synchronise first)."""
+        ms, cnt = ctypes.c_float(), ctypes.c_int()
+        _lib.check(self._lib.mips_scan_timing(self._h, ctypes.byref(ms), ctypes.byref(cnt), int(reset)),
+                   "mips_scan_timing")
+        return ms.value, cnt.value
+
     def last_scan_ms(self) -> float:
-        out = ctypes.c_float()
-        _lib.check(self._lib.mips_last_scan_ms(self._h, ctypes.byref(out)), "mips_last_scan_ms")
-        return out.value
+        import torch
+
+        torch.cuda.synchronize(self.device)
+        ms, cnt = self.scan_timing()
+        return ms / cnt if cnt else -1.0
 
     # ------------------------------------------------------------------ persistence
     # Own format (SURVEY.md section 5: the on-disk format is free, the call surface is kept):
@@ -256,6 +266,8 @@ def merge_topk(cand_s, cand_i, parts: int, k: int, metric: int = _lib.METRIC_IP)
 
     lib = _lib.load()
     nq = cand_s.shape[0]
+    if cand_s.shape != cand_i.shape or cand_s.shape[1] != parts * k:
+        raise ValueError(f"merge_topk: candidates {tuple(cand_s.shape)} / {tuple(cand_i.shape)} != [nq, parts*k = {parts * k}]")
     cand_s = cand_s.contiguous()
     cand_i = cand_i.contiguous()
     dev = cand_s.device.index

@@ -201,8 +201,10 @@ def test_merge_topk_kernel_padding_and_l2():
     i = torch.tensor([[9, 3, -1, 2, 7, -1]]).cuda()
     ms, mi = ram.merge_topk(s, i, 2, 3)
     assert mi.cpu().tolist() == [[2, 9, 3]] and ms.cpu().tolist() == [[5., 5., 4.]]
-    ms, mi = ram.merge_topk(s, i, 2, 6)
+    ms, mi = ram.merge_topk(s, i, 1, 6)
     assert mi.cpu().tolist() == [[2, 9, 3, 7, -1, -1]]
+    with pytest.raises(ValueError):
+        ram.merge_topk(s, i, 2, 6)
     s2 = torch.tensor([[1., 2., float("inf"), 0.5, 2., float("inf")]]).cuda()
     ms, mi = ram.merge_topk(s2, i, 2, 3, metric=ram.METRIC_L2)
     assert mi.cpu().tolist() == [[2, 9, 3]] and ms.cpu().tolist() == [[0.5, 1., 2.]]
