@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--queries", type=int, default=4096)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=5)
-    ap.add_argument("--cpu-queries", type=int, default=32, help="queries in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-queries", type=int, default=768, help="queries in the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 

@@ -148,6 +148,11 @@ int mips_l2_normalize(float* x_device, int64_t n, int64_t d, int device, void* h
 int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out_host, int device,
                         void* hip_stream);
 
+/* Tuning knobs of the scan launch (0 = automatic): "nsplit" = number of index splits (rounded up
+ * to a multiple of 8), "qgroups" = query-tile groups per XCD octet (1, 2, 4 or 8).  Results never
+ * depend on them; only speed does. */
+int mips_index_set_param(mips_index_t* index, const char* name, int64_t value);
+
 /* Timing hook used by bench.py: every mips_search records a HIP event pair around its fused scan
  * kernel on the search stream (a ring of 128 pairs).  Returns the summed duration in ms and the
  * number of scan launches recorded since the last reset (at most 128); the stream must have been

@@ -88,6 +88,7 @@ def _bind(lib):
         "mips_merge_topk": (i32, [vp, vp, i64, i32, i32, i32, vp, vp, i32, vp]),
         "mips_l2_normalize": (i32, [vp, i64, i64, i32, vp]),
         "mips_rows_max_sumsq": (i32, [vp, i64, i64, c.POINTER(c.c_double), i32, vp]),
+        "mips_index_set_param": (i32, [vp, c.c_char_p, i64]),
         "mips_scan_timing": (i32, [vp, c.POINTER(c.c_float), c.POINTER(c.c_int), i32]),
     }
     for name, (res, args) in sig.items():
@@ -102,7 +103,7 @@ EXPORTS = (
     "mips_index_reserve", "mips_index_add", "mips_index_reset", "mips_index_ntotal",
     "mips_index_dim", "mips_index_metric", "mips_index_phi", "mips_index_read_rows",
     "mips_index_add_synthetic", "mips_synth_fill", "mips_search", "mips_merge_topk",
-    "mips_l2_normalize", "mips_rows_max_sumsq", "mips_scan_timing",
+    "mips_l2_normalize", "mips_rows_max_sumsq", "mips_index_set_param", "mips_scan_timing",
 )
 
 

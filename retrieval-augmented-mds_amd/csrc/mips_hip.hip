@@ -96,6 +96,9 @@ struct mips_index {
     Buffer qbuf, part_s, part_i, stage, out_s, out_i, scalar;
     // ring of HIP event pairs around the scan kernel (bench.py reads the average launch duration)
     static constexpr int kEvRing = 128;
+    // tuning knobs (mips_index_set_param); 0 = automatic
+    int opt_nsplit = 0;
+    int opt_qgroups = 0;
     hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
     int ev_count = 0; // pairs recorded since the last reset (saturates at kEvRing)
     int ev_next = 0;
@@ -176,10 +179,14 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     const int64_t nq_pad = round_up(nq, mips::TN);
     const int nqt = (int)(nq_pad / mips::TN);
     const int ntiles = (int)((ix->ntotal + mips::TM - 1) / mips::TM);
-    // enough workgroups for two per CU; splits are a multiple of 8 (one XCD group each)
-    int nsplit = (int)round_up(std::max(1, (512 + nqt - 1) / nqt), 8);
+    // enough workgroups for two per CU; splits are a multiple of 8
+    int nsplit = ix->opt_nsplit > 0 ? (int)round_up(ix->opt_nsplit, 8) : (int)round_up(std::max(1, (512 + nqt - 1) / nqt), 8);
     nsplit = (int)std::min<int64_t>(nsplit, round_up(ntiles, 8));
     const int tps = (ntiles + nsplit - 1) / nsplit;
+    // query-tile groups per XCD: keep an XCD's query working set at <= 8 tiles (1.5 MiB of its 4 MiB L2)
+    int qgroups = ix->opt_qgroups;
+    if (qgroups != 1 && qgroups != 2 && qgroups != 4 && qgroups != 8) qgroups = nqt <= 8 ? 1 : nqt <= 16 ? 2 : nqt <= 32 ? 4 : 8;
+    const int qt_per_group = (nqt + qgroups - 1) / qgroups;
 
     const size_t ncand = (size_t)nsplit * 2 * KL;
     int rc = ix->part_s.ensure((size_t)nq_pad * ncand * sizeof(float));
@@ -197,6 +204,9 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     a.tiles_per_split = tps;
     a.nsplit = nsplit;
     a.nqt = nqt;
+    a.qgroups = qgroups;
+    a.qt_per_group = qt_per_group;
+    a.splits_per_group = nsplit / (8 / qgroups);
     a.part_s = (float*)ix->part_s.p;
     a.part_i = (int*)ix->part_i.p;
 
@@ -204,7 +214,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
                                 mips::SCAN_LDS_BYTES));
     const int slot = ix->ev_next;
     HIP_TRY(hipEventRecord(ix->ev0[slot], st));
-    mips::scan_kernel<KL><<<nqt * nsplit, mips::SCAN_THREADS, mips::SCAN_LDS_BYTES, st>>>(a);
+    mips::scan_kernel<KL><<<qt_per_group * qgroups * nsplit, mips::SCAN_THREADS, mips::SCAN_LDS_BYTES, st>>>(a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ix->ev1[slot], st));
     ix->ev_next = (slot + 1) % mips_index::kEvRing;
@@ -494,6 +504,15 @@ int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out
     (void)hipFree(slot);
     if (e != hipSuccess) return fail(MIPS_E_HIP, "mips_rows_max_sumsq: %s", hipGetErrorString(e));
     std::memcpy(out_host, &bits, 8);
+    return MIPS_OK;
+}
+
+int mips_index_set_param(mips_index_t* ix, const char* name, int64_t value) {
+    if (!ix || !name) return fail(MIPS_E_INVALID, "mips_index_set_param: bad argument");
+    const std::string n(name);
+    if (n == "nsplit") ix->opt_nsplit = (int)value;
+    else if (n == "qgroups") ix->opt_qgroups = (int)value;
+    else return fail(MIPS_E_INVALID, "mips_index_set_param: unknown parameter '%s'", name);
     return MIPS_OK;
 }
 

@@ -18,7 +18,7 @@
 // greater than the current K-th" implements the tie rule "lowest index wins" without comparing
 // indices.
 //
-// Work decomposition: grid = (#query tiles) x (#index splits, a multiple of 8).  A workgroup keeps
+// Work decomposition: grid = (#query tiles, padded to the group count) x (#index splits, a multiple of 8).  A workgroup keeps
 // its query tile and walks the document tiles of its split; the flattened (tile, k-step) sequence
 // is software pipelined (global loads of step s+1 in flight during the MFMAs of step s, LDS double
 // buffered, one barrier per step).  blockIdx is decoded so that all query tiles of one split share
@@ -51,6 +51,9 @@ struct ScanArgs {
     int tiles_per_split;
     int nsplit;           // multiple of 8
     int nqt;              // query tiles
+    int qgroups;          // QG in {1,2,4,8}: query-tile groups; XCD x serves group x % QG, split group x / QG
+    int qt_per_group;     // ceil(nqt / QG)
+    int splits_per_group; // nsplit / (8 / QG)
     float* part_s;        // [nq_pad][nsplit][2][KL]
     int* part_i;
 };
@@ -82,11 +85,15 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_kernel(ScanArgs p) {
     const int h = lane >> 5;
     const int l31 = lane & 31;
 
-    // XCD-aware decode: blocks with equal (blockIdx & 7) share an XCD / L2.
+    // XCD-aware decode: blocks with equal (blockIdx & 7) share an XCD and its 4 MiB L2.  Each XCD
+    // is given a GROUP of query tiles (its query working set, qt_per_group x 192 KiB, must stay L2
+    // resident next to the streaming document tiles) and a group of index splits; consecutive blocks
+    // of an XCD are the query tiles of ONE split, so they walk the same document tiles together.
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;
-    const int qt = j % p.nqt;
-    const int split = xcd + 8 * (j / p.nqt);
+    const int qt = (xcd % p.qgroups) + p.qgroups * (j % p.qt_per_group);
+    const int split = (xcd / p.qgroups) * p.splits_per_group + j / p.qt_per_group;
+    if (qt >= p.nqt) return; // padding block of the last query group (whole workgroup leaves)
 
     const int t0 = split * p.tiles_per_split;
     int t1 = t0 + p.tiles_per_split;

@@ -166,6 +166,10 @@ class MipsIndex:
         del keep
         return D, I
 
+    def set_param(self, name: str, value: int) -> None:
+        """Launch tuning knob ("nsplit", "qgroups"); never changes results."""
+        _lib.check(self._lib.mips_index_set_param(self._h, name.encode(), int(value)), "mips_index_set_param")
+
     def scan_timing(self, reset: bool = False):
         """(summed ms, launches) of the fused scan kernel since the last reset, from HIP events on
         the search stream (synchronise first)."""

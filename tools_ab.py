@@ -1,0 +1,42 @@
+"""A/B harness (GPU box): times scan-kernel launch variants interleaved in ONE process.
+usage: python tools_ab.py "qgroups=1" "qgroups=4" "qgroups=4,nsplit=32" ... [--rows N --queries Q --rounds R]"""
+import argparse, json, sys, os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np, torch
+import retrieval_augmented_mds_amd as ram
+from oracle import synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("variants", nargs="+")
+ap.add_argument("--rows", type=int, default=1 << 20)
+ap.add_argument("--queries", type=int, default=4096)
+ap.add_argument("--dim", type=int, default=768)
+ap.add_argument("--k", type=int, default=5)
+ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--iters", type=int, default=5)
+a = ap.parse_args()
+ix = ram.MipsIndex(a.dim)
+ix.add_synthetic(a.rows, 0, synth.SEED_DOCS, synth.KIND_GAUSS)
+q = ram.synth_fill(a.queries, a.dim, 0, synth.SEED_QUERIES, synth.KIND_GAUSS)
+ref = None
+res = {v: [] for v in a.variants}
+for r in range(a.rounds):
+    for v in a.variants:
+        params = dict(kv.split("=") for kv in v.split(",") if kv)
+        for name in ("nsplit", "qgroups", "variant"):
+            try:
+                ix.set_param(name, int(params.get(name, 0)))
+            except RuntimeError:
+                pass
+        s, i = ix.search(q, a.k); torch.cuda.synchronize()
+        if ref is None: ref = (s.clone(), i.clone())
+        assert torch.equal(i, ref[1]) and torch.equal(s, ref[0]), f"variant {v} changed results"
+        ix.scan_timing(reset=True)
+        for _ in range(a.iters): ix.search(q, a.k)
+        torch.cuda.synchronize()
+        ms, n = ix.scan_timing()
+        res[v].append(ms / n)
+fl = 2.0 * a.queries * a.rows * a.dim
+for v, t in res.items():
+    t = np.array(t)
+    print(f"{v:32s} median {np.median(t):8.3f} ms  min {t.min():8.3f} ms  -> {fl / np.median(t) / 1e9:7.1f} TFLOP/s (median)", flush=True)
