@@ -149,7 +149,8 @@ int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out
                         void* hip_stream);
 
 /* Tuning knobs of the scan launch (0 = automatic): "nsplit" = number of index splits (rounded up
- * to a multiple of 8), "qgroups" = query-tile groups per XCD octet (1, 2, 4 or 8).  Results never
+ * to a multiple of 8), "qgroups" = query-tile groups per XCD octet (1, 2, 4 or 8), "variant" = scan kernel (1 = 128x128
+ * register-staged tiles, 3 = query-stationary LDS-DMA, used when d pads to 768).  Results never
  * depend on them; only speed does. */
 int mips_index_set_param(mips_index_t* index, const char* name, int64_t value);
 

@@ -13,6 +13,7 @@
 #include "../../include/mips_hip.h"
 #include "aux_kernels.hpp"
 #include "scan_kernel.hpp"
+#include "scan_kernel_v3.hpp"
 
 namespace {
 
@@ -50,6 +51,8 @@ struct DeviceGuard {
 };
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+constexpr int64_t kRowAlign = 256;   // index capacity granule: the largest document tile of any scan variant
+constexpr int64_t kQueryAlign = 256; // query staging buffer granule: the largest query tile of any scan variant
 
 struct Buffer {
     void* p = nullptr;
@@ -99,6 +102,8 @@ struct mips_index {
     // tuning knobs (mips_index_set_param); 0 = automatic
     int opt_nsplit = 0;
     int opt_qgroups = 0;
+    int opt_sub = 0;
+    int opt_variant = 0; // 1 = scan_kernel (128x128 tiles, register staged), 3 = scan_kernel_v3 (query-stationary, LDS-DMA)
     hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
     int ev_count = 0; // pairs recorded since the last reset (saturates at kEvRing)
     int ev_next = 0;
@@ -109,7 +114,7 @@ namespace {
 int grow(mips_index* ix, int64_t need_rows, hipStream_t st) {
     if (need_rows <= ix->capacity) return MIPS_OK;
     int64_t cap = std::max<int64_t>(need_rows, ix->capacity + ix->capacity / 2);
-    cap = round_up(cap, mips::TM);
+    cap = round_up(cap, kRowAlign);
     uint16_t* fresh = nullptr;
     const size_t bytes = (size_t)cap * ix->ld * sizeof(uint16_t);
     hipError_t e = hipMalloc((void**)&fresh, bytes);
@@ -176,19 +181,33 @@ int compute_phi(mips_index* ix, hipStream_t st) {
 template <int KL>
 int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_out_i, int64_t idx_offset,
                   hipStream_t st) {
-    const int64_t nq_pad = round_up(nq, mips::TN);
-    const int nqt = (int)(nq_pad / mips::TN);
-    const int ntiles = (int)((ix->ntotal + mips::TM - 1) / mips::TM);
-    // enough workgroups for two per CU; splits are a multiple of 8
-    int nsplit = ix->opt_nsplit > 0 ? (int)round_up(ix->opt_nsplit, 8) : (int)round_up(std::max(1, (512 + nqt - 1) / nqt), 8);
+    // variant 3 (query-stationary, LDS-DMA) needs the whole K of 32 queries in 192 VGPRs: d padded to 768
+    int variant = ix->opt_variant;
+    if (variant != 1 && variant != 3) variant = 3;
+    if (ix->ld != 768) variant = 1;
+    const int tm = variant == 1 ? mips::TM : mips::V3_DB;             // documents per scheduling unit ("tile")
+    const int tn = variant == 1 ? mips::TN : mips::V3_TN;             // queries per workgroup
+    const int lists = 2;                                              // running lists per (query, split)
+    const int wg_target = variant == 1 ? 512 : 256;                   // resident workgroups on 256 CUs
+    const int64_t nq_pad = round_up(nq, kQueryAlign);
+    const int nqt = (int)((nq + tn - 1) / tn);
+    const int ntiles = (int)((ix->ntotal + tm - 1) / tm);
+    int nsplit = ix->opt_nsplit > 0 ? (int)round_up(ix->opt_nsplit, 8)
+                                    : (int)round_up(std::max(1, (wg_target + nqt - 1) / nqt), 8);
     nsplit = (int)std::min<int64_t>(nsplit, round_up(ntiles, 8));
     const int tps = (ntiles + nsplit - 1) / nsplit;
-    // query-tile groups per XCD: keep an XCD's query working set at <= 8 tiles (1.5 MiB of its 4 MiB L2)
+    // query-tile groups per XCD.  Variant 1 re-reads its query tiles from L2 for every document tile:
+    // keep an XCD's query working set at <= 8 tiles (1.5 MiB of its 4 MiB L2).  Variant 3 holds the
+    // queries in registers: give every XCD as many query tiles of ONE split as possible instead, so a
+    // document block is fetched from HBM once and served to the other tiles from that XCD's L2.
     int qgroups = ix->opt_qgroups;
-    if (qgroups != 1 && qgroups != 2 && qgroups != 4 && qgroups != 8) qgroups = nqt <= 8 ? 1 : nqt <= 16 ? 2 : nqt <= 32 ? 4 : 8;
+    if (qgroups != 1 && qgroups != 2 && qgroups != 4 && qgroups != 8) {
+        if (variant == 1) qgroups = nqt <= 8 ? 1 : nqt <= 16 ? 2 : nqt <= 32 ? 4 : 8;
+        else qgroups = nqt <= 32 ? 1 : nqt <= 64 ? 2 : nqt <= 128 ? 4 : 8;
+    }
     const int qt_per_group = (nqt + qgroups - 1) / qgroups;
 
-    const size_t ncand = (size_t)nsplit * 2 * KL;
+    const size_t ncand = (size_t)nsplit * lists * KL;
     int rc = ix->part_s.ensure((size_t)nq_pad * ncand * sizeof(float));
     if (rc) return rc;
     rc = ix->part_i.ensure((size_t)nq_pad * ncand * sizeof(int));
@@ -210,11 +229,28 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     a.part_s = (float*)ix->part_s.p;
     a.part_i = (int*)ix->part_i.p;
 
-    HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel<KL>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                mips::SCAN_LDS_BYTES));
+    const int grid = qt_per_group * qgroups * nsplit;
     const int slot = ix->ev_next;
-    HIP_TRY(hipEventRecord(ix->ev0[slot], st));
-    mips::scan_kernel<KL><<<qt_per_group * qgroups * nsplit, mips::SCAN_THREADS, mips::SCAN_LDS_BYTES, st>>>(a);
+    if (variant == 1) {
+        HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel<KL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    mips::SCAN_LDS_BYTES));
+        HIP_TRY(hipEventRecord(ix->ev0[slot], st));
+        mips::scan_kernel<KL><<<grid, mips::SCAN_THREADS, mips::SCAN_LDS_BYTES, st>>>(a);
+    } else {
+        constexpr int KS16 = 48;
+        constexpr int lds = mips::V3_STAGES * mips::V3_DB * KS16 * 32;
+        const int sub = ix->opt_sub; // experiment selector: 0 = 8 waves x 32 queries, 1 = 4 waves x 64 queries
+        auto go = [&](auto kern, int threads) -> int {
+            HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            HIP_TRY(hipEventRecord(ix->ev0[slot], st));
+            kern<<<grid, threads, lds, st>>>(a);
+            return MIPS_OK;
+        };
+        int rc2;
+        if (sub == 1 && KL == 8) rc2 = go(mips::scan_kernel_v3<KL, KS16, 2, 6>, 256);
+        else rc2 = go(mips::scan_kernel_v3<KL, KS16, 1, 3>, 512);
+        if (rc2) return rc2;
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ix->ev1[slot], st));
     ix->ev_next = (slot + 1) % mips_index::kEvRing;
@@ -302,7 +338,7 @@ int mips_index_reserve(mips_index_t* ix, int64_t n) {
     DeviceGuard g(ix->device);
     if (n <= ix->capacity) return MIPS_OK;
     // exact reservation (no geometric slack)
-    int64_t cap = round_up(n, mips::TM);
+    int64_t cap = round_up(n, kRowAlign);
     uint16_t* fresh = nullptr;
     const size_t bytes = (size_t)cap * ix->ld * 2;
     hipError_t e = hipMalloc((void**)&fresh, bytes);
@@ -434,7 +470,7 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
             int rc = compute_phi(ix, st);
             if (rc) return rc;
         }
-        const int64_t nq_pad = round_up(nq, mips::TN);
+        const int64_t nq_pad = round_up(nq, kQueryAlign);
         int rc = ix->qbuf.ensure((size_t)nq_pad * ix->ld * 2);
         if (rc) return rc;
         uint16_t* qb = (uint16_t*)ix->qbuf.p;
@@ -512,6 +548,8 @@ int mips_index_set_param(mips_index_t* ix, const char* name, int64_t value) {
     const std::string n(name);
     if (n == "nsplit") ix->opt_nsplit = (int)value;
     else if (n == "qgroups") ix->opt_qgroups = (int)value;
+    else if (n == "variant") ix->opt_variant = (int)value;
+    else if (n == "sub") ix->opt_sub = (int)value;
     else return fail(MIPS_E_INVALID, "mips_index_set_param: unknown parameter '%s'", name);
     return MIPS_OK;
 }
