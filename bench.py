@@ -135,10 +135,24 @@ def main():
     bytes_ = local_rows * d * 2.0 + nq * d * 2.0 + nq * k * 12.0
     ach_tflops = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
     ach_gbs = bytes_ / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    # HBM-side traffic of one scan launch: PMC counters cannot be read from inside this process, so the
+    # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/<round>/),
+    # corrected as MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE counts wide reads at half: x2), and
+    # is only reported when that profile was taken on the same workload; otherwise null.
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
+            t = json.load(f)
+        if (t["rows_per_gpu"], t["dim"], t["queries"], t["k"]) == (local_rows, d, nq, k):
+            traffic = (2.0 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0
+            traffic_src = t["source"]
+    except Exception:
+        pass
     roofline = {
         "bound": "mfma", "achieved": ach_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-        "frac": ach_tflops / PEAK_BF16_TFLOPS, "traffic": None,
-        "kernel": "mips::scan_kernel<8>", "kernel_ms": scan_ms, "launches_timed": scan_launches,
+        "frac": ach_tflops / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+        "kernel": "mips::scan_kernel_v3<8, 48, 1, 2, true, 0, true>", "kernel_ms": scan_ms,
+        "launches_timed": scan_launches,
         "flops_per_launch": flops, "bytes_per_launch": bytes_,
         "hbm_achieved": ach_gbs, "hbm_peak": PEAK_HBM_GBS, "hbm_unit": "GB/s", "hbm_frac": ach_gbs / PEAK_HBM_GBS,
         "note": "Q=4096 flop per index byte >> ~310 flop/B ridge: MFMA-bound; hbm_* = literal HBM-read fraction",

@@ -96,7 +96,7 @@ struct mips_index {
     uint16_t* rows = nullptr;
     bool phi_valid = false;
     double phi = 0.0;
-    Buffer qbuf, part_s, part_i, stage, out_s, out_i, scalar;
+    Buffer qbuf, part_s, part_i, stage, out_s, out_i, scalar, gthr;
     // ring of HIP event pairs around the scan kernel (bench.py reads the average launch duration)
     static constexpr int kEvRing = 128;
     // tuning knobs (mips_index_set_param); 0 = automatic
@@ -184,7 +184,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // variant 3 (query-stationary, LDS-DMA) needs the whole K of 32 queries in 192 VGPRs: d padded to 768
     int variant = ix->opt_variant;
     if (variant != 1 && variant != 3) variant = 3;
-    if (ix->ld != 768) variant = 1;
+    if (ix->ld != 768 || KL != 8) variant = 1; // v3 register budget: 192 fragment + 16 list VGPRs of 256
     const int tm = variant == 1 ? mips::TM : mips::V3_DB;             // documents per scheduling unit ("tile")
     const int tn = variant == 1 ? mips::TN : mips::V3_TN;             // queries per workgroup
     const int lists = 2;                                              // running lists per (query, split)
@@ -228,6 +228,13 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     a.splits_per_group = nsplit / (8 / qgroups);
     a.part_s = (float*)ix->part_s.p;
     a.part_i = (int*)ix->part_i.p;
+    a.gthr = nullptr;
+    if (variant == 3) {
+        rc = ix->gthr.ensure((size_t)nq_pad * 2 * sizeof(unsigned)); // one slot per (query, lane half)
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(ix->gthr.p, 0, (size_t)nq_pad * 2 * sizeof(unsigned), st));
+        a.gthr = (unsigned*)ix->gthr.p;
+    }
 
     const int grid = qt_per_group * qgroups * nsplit;
     const int slot = ix->ev_next;
@@ -236,9 +243,9 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
                                     mips::SCAN_LDS_BYTES));
         HIP_TRY(hipEventRecord(ix->ev0[slot], st));
         mips::scan_kernel<KL><<<grid, mips::SCAN_THREADS, mips::SCAN_LDS_BYTES, st>>>(a);
-    } else {
+    } else if constexpr (KL == 8) {
         constexpr int KS16 = 48;
-        constexpr int lds = mips::V3_STAGES * mips::V3_DB * KS16 * 32;
+        constexpr int lds = mips::V3_STAGES * mips::V3_DB * KS16 * 32 + 8 * 64 * 4; // ring + threshold slots
         const int sub = ix->opt_sub; // experiment selector: 0 = 8 waves x 32 queries, 1 = 4 waves x 64 queries
         auto go = [&](auto kern, int threads) -> int {
             HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -246,10 +253,17 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             kern<<<grid, threads, lds, st>>>(a);
             return MIPS_OK;
         };
-        int rc2;
-        if (sub == 1 && KL == 8) rc2 = go(mips::scan_kernel_v3<KL, KS16, 2, 6>, 256);
-        else rc2 = go(mips::scan_kernel_v3<KL, KS16, 1, 3>, 512);
+        int rc2;   // sub: A/B selector for tools_ab.py (0 = shipped configuration)
+        if (sub == 1) rc2 = go(mips::scan_kernel_v3<KL, KS16, 2, 6, true, 0, false>, 256);       // 4 waves x 64 queries
+        else if (sub == 2) rc2 = go(mips::scan_kernel_v3<KL, KS16, 1, 2, false>, 512);            // DMA issued in one burst
+        else if (sub == 4) rc2 = go(mips::scan_kernel_v3<KL, KS16, 1, 2, true, 0, false>, 512);   // no shared thresholds
+        else if (sub == 5) rc2 = go(mips::scan_kernel_v3<KL, KS16, 1, 3, true>, 512);             // prefetch depth 3
+        else if (sub == 8) rc2 = go(mips::scan_kernel_v3<KL, KS16, 1, 2, true, 1>, 512);          // timing only: no epilogue
+        else if (sub == 9) rc2 = go(mips::scan_kernel_v3<KL, KS16, 1, 2, true, 2>, 512);          // timing only: pre-test only
+        else rc2 = go(mips::scan_kernel_v3<KL, KS16, 1, 2, true>, 512);
         if (rc2) return rc2;
+    } else {
+        return fail(MIPS_E_UNSUPPORTED, "internal: scan variant 3 requires K' = 8");
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ix->ev1[slot], st));
@@ -325,6 +339,7 @@ int mips_index_destroy(mips_index_t* ix) {
     ix->out_s.release();
     ix->out_i.release();
     ix->scalar.release();
+    ix->gthr.release();
     for (int e = 0; e < mips_index::kEvRing; ++e) {
         if (ix->ev0[e]) (void)hipEventDestroy(ix->ev0[e]);
         if (ix->ev1[e]) (void)hipEventDestroy(ix->ev1[e]);

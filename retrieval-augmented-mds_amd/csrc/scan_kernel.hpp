@@ -56,7 +56,17 @@ struct ScanArgs {
     int splits_per_group; // nsplit / (8 / QG)
     float* part_s;        // [nq_pad][nsplit][2][KL]
     int* part_i;
+    unsigned* gthr;       // [nq_pad] shared per-query thresholds (order-preserving keys, 0 = none), v3 only
 };
+
+// order-preserving map float -> uint32 (larger float <=> larger key); key 0 is below every float
+__device__ __forceinline__ unsigned thr_encode(float f) {
+    const unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float thr_decode(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
 
 // sorted (descending) K-list kept in registers; `s` is known to be > ls[KL-1]
 template <int KL>

@@ -38,10 +38,39 @@ template <int NQB> struct V3Cfg {
     static constexpr int THREADS = 64 * WAVES;
 };
 
+// inline asm is device-only: the host pass parses kernel bodies too and must not see GPU constraints
+__device__ __forceinline__ void keep_alive(const f32x16& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"v"(v));
+#else
+    (void)v;
+#endif
+}
+
+__device__ __forceinline__ void keep_alive_f(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"v"(v));
+#else
+    (void)v;
+#endif
+}
+
+// no-return buffer_atomic_umax through the (shifted) threshold descriptor: the slot offset is the VGPR the
+// lane already holds, so publishing needs no 64-bit address registers (the kernel sits at the 256-VGPR
+// cap).  No VGPR destination => nothing for hipcc's waitcnt bookkeeping to miss; it only makes the
+// counted vmcnt waits more conservative.  s_nop 4: SGPR-written-by-SALU -> VMEM descriptor read hazard.
+__device__ __forceinline__ void publish_umax(unsigned key, unsigned voff, __amdgpu_buffer_rsrc_t rsrc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 4\n\tbuffer_atomic_umax %0, %1, %2, 0 offen" ::"v"(key), "v"(voff), "s"(rsrc) : "memory");
+#else
+    (void)key; (void)voff; (void)rsrc;
+#endif
+}
+
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
-template <int KL, int KS16, int NQB, int AD>
+template <int KL, int KS16, int NQB, int AD, bool DMA_SPREAD, int TIMING_MODE = 0, bool GLOBAL_THR = true>
 __global__ __launch_bounds__(V3Cfg<NQB>::THREADS, NQB == 1 ? 2 : 1) void scan_kernel_v3(ScanArgs p) {
     constexpr int WAVES = V3Cfg<NQB>::WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -77,45 +106,91 @@ __global__ __launch_bounds__(V3Cfg<NQB>::THREADS, NQB == 1 ? 2 : 1) void scan_ke
         // Consume the fragments here: the compiler's wait for these ordinary loads then sits BEFORE the
         // pipeline instead of inside the loop (where a vmcnt(0) would drain the LDS-DMA queue every
         // block), and the values stay opaque register residents.
+        // (NQB == 2: 384 fragment registers exceed the 256 architectural VGPRs; the first 256 are pinned
+        // in the accumulation half of the unified file -- MFMA reads B operands from AGPRs directly --
+        // otherwise hipcc treats AGPRs as spill space and copies 4 registers back before every MFMA.)
 #pragma unroll
-        for (int s = 0; s < KS16; ++s) asm volatile("" : "+v"(bq[n][s]));
+        for (int s = 0; s < KS16; ++s) {
+            if (NQB == 2 && (n * KS16 + s) * 4 < 256) asm volatile("" : "+a"(bq[n][s]));
+            else asm volatile("" : "+v"(bq[n][s]));
+        }
     }
 
     float ls[NQB][KL];
     int li[NQB][KL];
+    // Insert threshold of a list: max(own K'-th best, bound from the shared per-query thresholds below).
+    // (Exchanging bounds between lanes l and l + 32 -- same query, other rows -- was measured: the max of
+    // the two K'-th bests is neutral, the exact K'-th of the pair union costs more than it saves.)
+    float thr[NQB];
 #pragma unroll
-    for (int n = 0; n < NQB; ++n)
+    for (int n = 0; n < NQB; ++n) {
+        thr[n] = -INFINITY;
 #pragma unroll
         for (int i = 0; i < KL; ++i) {
             ls[n][i] = -INFINITY;
             li[n][i] = IDX_NONE;
         }
+    }
+
+    // ---- shared per-query thresholds.  All lists of a query (16+ splits x 2 lane halves, in different
+    // workgroups) publish their K'-th best score with an order-preserving atomicMax; every wave re-reads
+    // the 32 values of its queries once per block through one extra 256-byte LDS-DMA.  A document can
+    // only belong to the query's global top-K' if its score is >= every published value g (each g is
+    // some list's K'-th best, hence <= the global K'-th best), so the insert test becomes
+    //     s > max(own K'-th, nextbelow(g))      i.e.  s > own  and  s >= g
+    // -- ties with g are kept, the strict rule applies to the own list only, and a stale g (L1, DMA in
+    // flight) is merely a weaker bound.  This removes the per-list warm-up: ~K' ln(N/K') inserts per
+    // QUERY instead of per list.
+    // Layout of p.gthr: [query tile][wave][lane] (one slot per lane: lanes l and l + 32 of a query keep
+    // separate slots and exchange by shuffle, the same lane of OTHER splits shares the slot), so a wave's
+    // 64 slots are contiguous: one buffer_load_dword ... lds refreshes them.  thr_addr is this lane's
+    // slot in the LDS threshold area and, with the descriptor base shifted by the area offset, also the
+    // DMA's voffset -- one persistent VGPR for both.
+    constexpr unsigned THR_AREA = V3_STAGES * STAGE_BYTES;
+    const unsigned thr_addr = THR_AREA + wave * 256 + lane * 4;
+    __amdgpu_buffer_rsrc_t thr_rsrc;
+    if (GLOBAL_THR) {
+        *reinterpret_cast<unsigned*>(smem + thr_addr) = 0u;
+        thr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(reinterpret_cast<unsigned char*>(p.gthr) + (int64_t)qt * (WAVES * 256) - (int64_t)THR_AREA), 0,
+            (int)(THR_AREA + WAVES * 256), 0x00020000);
+    }
 
     // ---- LDS-DMA map: piece pc = slab * 4 + rg covers rows 8 rg .. 8 rg + 7 of 64-k slab `slab`;
     // lane -> row 8 rg + (lane >> 3), slot lane & 7, source chunk slot ^ ((row >> 1) & 7)
     // = slot ^ ((4 rg + (lane >> 4)) & 7): depends on rg only through rg & 1.
     const int lrow = lane >> 3;
+    // odd row groups: slot ^ 4, i.e. byte offset ^ 64 (row pitch is a multiple of 128 B) -- derived per
+    // piece instead of held in a second register
     const unsigned lane_off0 = (unsigned)(lrow * p.ld * 2 + (((lane & 7) ^ ((lane >> 4) & 7)) << 4));
-    const unsigned lane_off1 = (unsigned)(lrow * p.ld * 2 + (((lane & 7) ^ ((4 + (lane >> 4)) & 7)) << 4));
     const unsigned char* docs_b = reinterpret_cast<const unsigned char*>(p.docs);
     const int64_t row_bytes = (int64_t)p.ld * 2;
 
-    auto issue = [&](int blk, int stage) {
-        const unsigned char* bbase = docs_b + (int64_t)blk * V3_DB * row_bytes;
+    // one DMA piece (i-th of this wave) of document block `blk` into ring stage `stage`:
+    // buffer_load_dwordx4 ... offen lds -- descriptor (rebased per block, 48 KiB window, so the hardware
+    // range check also fences the last block) and piece offset in SGPRs, the lane part in ONE VGPR.
+    auto issue_piece = [&](const unsigned char* blk_base, int stage, int i) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void*)blk_base, 0, (int)(V3_DB * row_bytes), 0x00020000);
         unsigned char* sbase = smem + stage * STAGE_BYTES;
+        const int pc = wave + WAVES * i;
+        const int slab = pc >> 2, rg = pc & 3;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(sbase + pc * 1024), 16,
+                                                 (rg & 1) ? (lane_off0 ^ 64u) : lane_off0,
+                                                 rg * 8 * (int)row_bytes + slab * 128, 0, 0);
+    };
+    auto issue = [&](const unsigned char* blk_base, int stage) {
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int pc = wave + WAVES * i;
-            const int slab = pc >> 2, rg = pc & 3;
-            const unsigned char* src = bbase + (int64_t)rg * 8 * row_bytes + slab * 128 + ((rg & 1) ? lane_off1 : lane_off0);
-            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sbase + pc * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < PPW; ++i) issue_piece(blk_base, stage, i);
     };
 
     const int rd_row = l31 * 128;
     const int rd_swz = (l31 >> 1) & 7;
 
-    auto block = [&](int blk, int stage) {
+    // scores block `blk` (ring stage `stage`); when pblk >= 0 the DMA pieces of block pblk are issued
+    // one at a time between the MFMAs (spread over the chain: the partner wave keeps the matrix pipe busy
+    // during an issue, which right after the barrier it could not, both waves being there together)
+    auto block = [&](int blk, int stage, const unsigned char* pbase, int pstage) {
         const unsigned char* sa = smem + stage * STAGE_BYTES + rd_row;
         auto lds_frag = [&](int s) {
             return *reinterpret_cast<const bf16x8*>(sa + (s >> 2) * 4096 + (((2 * (s & 3) + h) ^ rd_swz) << 4));
@@ -131,6 +206,9 @@ __global__ __launch_bounds__(V3Cfg<NQB>::THREADS, NQB == 1 ? 2 : 1) void scan_ke
         bf16x8 ar[AD];
 #pragma unroll
         for (int s = 0; s < AD; ++s) ar[s] = lds_frag(s);
+        if (GLOBAL_THR && NQB == 1) { // first VMEM op of the block: covered by the next block's counted wait
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rsrc, (lds_void*)(smem + THR_AREA + wave * 256), 4, thr_addr, 0, 0, 16);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KS16; ++s) {
@@ -138,9 +216,15 @@ __global__ __launch_bounds__(V3Cfg<NQB>::THREADS, NQB == 1 ? 2 : 1) void scan_ke
             for (int n = 0; n < NQB; ++n)
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[s % AD], bq[n][s], acc[n], 0, 0, 0);
             if (s + AD < KS16) ar[s % AD] = lds_frag(s + AD);
+            if (DMA_SPREAD && (s % (KS16 / PPW)) == (KS16 / PPW) / 2) issue_piece(pbase, pstage, s / (KS16 / PPW));
             __builtin_amdgcn_sched_barrier(0);
         }
-        const int base = blk * V3_DB + 4 * h;
+        if (TIMING_MODE == 1) { // diagnostic builds only (results are wrong): 1 = no epilogue at all
+#pragma unroll
+            for (int n = 0; n < NQB; ++n) keep_alive(acc[n]);
+            return;
+        }
+        const int base = blk * V3_DB + (int)((thr_addr >> 5) & 4u); // + 4 * (lane >> 5), from the lane * 4 bits
         if ((int64_t)(blk + 1) * V3_DB > p.ntotal) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -149,38 +233,58 @@ __global__ __launch_bounds__(V3Cfg<NQB>::THREADS, NQB == 1 ? 2 : 1) void scan_ke
                     for (int n = 0; n < NQB; ++n) acc[n][r] = -INFINITY;
                 }
         }
+        if (GLOBAL_THR && NQB == 1) {
+            const unsigned key = *reinterpret_cast<const unsigned*>(smem + thr_addr); // an earlier block's DMA (or 0)
+            thr[0] = fmaxf(thr[0], key > 1u ? thr_decode(key - 1u) : -INFINITY);
+        }
 #pragma unroll
         for (int n = 0; n < NQB; ++n) {
             float mx = acc[n][0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[n][r]);
-            if (__ballot(mx > ls[n][KL - 1]) != 0ull) {
+            if (TIMING_MODE == 2) { // 2 = pre-test only, slow path never taken
+                if (__ballot(mx > thr[n]) != 0ull) keep_alive_f(mx); // branch taken as often as the real one
+                continue;
+            }
+            if (__ballot(mx > thr[n]) != 0ull) {
+                const float thr_in = thr[n];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float s = acc[n][r];
-                    if (s > ls[n][KL - 1]) list_insert<KL>(ls[n], li[n], s, base + (r & 3) + 8 * (r >> 2));
+                    if (s > thr[n]) {
+                        list_insert<KL>(ls[n], li[n], s, base + (r & 3) + 8 * (r >> 2));
+                        thr[n] = fmaxf(thr[n], ls[n][KL - 1]);
+                    }
                 }
+                if (GLOBAL_THR && NQB == 1 && ls[n][KL - 1] > thr_in) // own K'-th now beats every bound seen: publish
+                    publish_umax(thr_encode(ls[n][KL - 1]), thr_addr, thr_rsrc);
             }
         }
     };
 
-    // block i lives in ring stage i % 3 and is issued two blocks ahead
-    if (nb > 0) issue(b0, 0);
-    if (nb > 1) issue(b0 + 1, 1);
+    // Block i lives in ring stage i % 3 and is issued two blocks ahead.  The issue is unconditional:
+    // past the end of the split the LAST block is fetched again into a stage nobody reads any more, which
+    // keeps the MFMA chain free of branches and the vmcnt arithmetic uniform.
+    const unsigned char* first = docs_b + (int64_t)b0 * V3_DB * row_bytes;
+    const unsigned char* last = docs_b + (int64_t)(b1 - 1) * V3_DB * row_bytes;
+    const int64_t blk_bytes = V3_DB * row_bytes;
+    if (nb > 0) {
+        issue(first, 0);
+        issue(nb > 1 ? first + blk_bytes : last, 1);
+    }
+    const unsigned char* pbase = nb > 2 ? first + 2 * blk_bytes : last;
     int stage = 0, pstage = 2;
     for (int i = 0; i < nb; ++i) {
         // this wave's pieces of block i have landed once at most block i+1's remain in flight
-        if (i + 1 < nb) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + ((GLOBAL_THR && NQB == 1) ? 1 : 0)) : "memory");
         __builtin_amdgcn_s_barrier(); // all shares of block i landed; everyone is done with block i-1
-        if (i + 2 < nb) issue(b0 + i + 2, pstage);
-        block(b0 + i, stage);
+        if (!DMA_SPREAD) issue(pbase, pstage);
+        block(b0 + i, stage, pbase, pstage);
+        if (i + 3 < nb) pbase += blk_bytes; // stops at the last block
         stage = stage == 2 ? 0 : stage + 1;
         pstage = pstage == 2 ? 0 : pstage + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no DMA may outlive the workgroup's LDS allocation
 
 #pragma unroll
     for (int n = 0; n < NQB; ++n) {
