@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--cpu-queries", type=int, default=768, help="queries in the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N > 1 path on ONE GPU (all ranks on cuda:0, host-staged collective)")
     return ap.parse_args()
 
 
@@ -89,10 +91,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.backend == "gloo":
+        local_rank = 0  # rehearsal: every rank shares the one visible GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group("gloo")
 
     n, d, nq, k = args.rows, args.dim, args.queries, args.k
     index = ram.ShardedMipsIndex(d, metric=ram.METRIC_IP, device=local_rank)
@@ -120,9 +127,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank must hold the same global answer
+        chk = torch.stack([i.sum().to(torch.float64), s.double().sum()]).to(t.device)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise SystemExit("ranks disagree on the merged top-k")
     scan_ms_sum, scan_launches = index.local.scan_timing()
     scan_ms = scan_ms_sum / max(1, scan_launches)
 

@@ -110,14 +110,19 @@ class ShardedMipsIndex:
         if as_numpy:
             s, i = torch.from_numpy(np.ascontiguousarray(s)), torch.from_numpy(np.ascontiguousarray(i))
         backend = dist.get_backend(self.group)
+        home = s.device
         if backend == "nccl" and not s.is_cuda:
-            dev = f"cuda:{self.local.device}" if self.local is not None else "cuda"
-            s, i = s.to(dev), i.to(dev)
+            home = torch.device(f"cuda:{self.local.device}" if self.local is not None else "cuda")
+            s, i = s.to(home), i.to(home)
         packed = pack_topk(s, i)
+        if backend == "gloo" and packed.is_cuda:
+            packed = packed.cpu()  # rehearsal / CPU clusters: gloo moves host memory; RCCL takes the device tensor
         nq = packed.shape[0]
         # rank-major concatenation along dim 0 (the layout both RCCL and gloo accept)
         gathered = torch.empty((self.world * nq,) + tuple(packed.shape[1:]), dtype=torch.int64, device=packed.device)
         dist.all_gather_into_tensor(gathered, packed, group=self.group)  # the ONE collective of the path
+        if gathered.device != home:
+            gathered = gathered.to(home)
         cs, ci = unpack_gathered(gathered.view((self.world, nq) + tuple(packed.shape[1:])), self.world)
         out_s, out_i = self._merge(cs, ci, self.world, k, self.metric_type)
         if as_numpy:

@@ -326,3 +326,38 @@ def test_cfg2_full_size_properties_and_oracle_subset():
         del part
     ms, mi = ram.merge_topk(torch.cat(ps, 1), torch.cat(pi, 1), 2, k)
     assert np.array_equal(mi.cpu().numpy(), i) and np.array_equal(ms.cpu().numpy(), s)
+
+
+# ------------------------------------------------------------------ N > 1 on one GPU (gloo rehearsal)
+def _rank_worker(rank, world, port, n, nq, d, k, ret):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        ix = ram.ShardedMipsIndex(d, device=0)          # real HIP local search + device merge kernel
+        ix.add_synthetic_global(n, synth.SEED_DOCS, synth.KIND_GAUSS)
+        q = ram.synth_fill(nq, d, 0, synth.SEED_QUERIES, synth.KIND_GAUSS)
+        s, i = ix.search(q, k)
+        torch.cuda.synchronize()
+        x = synth.generate(synth.SEED_DOCS, 0, n, d, synth.KIND_GAUSS)
+        es, ei = orc.search_exact(q.float().cpu().numpy(), x, k)
+        lo, hi = ram.shard_bounds(n, world, rank)
+        ret[rank] = bool(np.array_equal(i.cpu().numpy(), ei) and np.array_equal(s.cpu().numpy(), es)
+                         and ix.local.ntotal == hi - lo)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_index_multi_rank_on_one_gpu(world):
+    """Row shards on `world` processes sharing cuda:0: real device scan per shard, packed all-gather
+    (gloo, host staged), device merge -- must equal the oracle on the unsharded index."""
+    import torch.multiprocessing as mp
+
+    port = 29600 + (os.getpid() % 2000) + world
+    ret = mp.Manager().dict()
+    mp.spawn(_rank_worker, args=(world, port, 50001, 200, 768, 5, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
