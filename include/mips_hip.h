@@ -50,6 +50,8 @@ extern "C" {
 /* mips_search flags */
 #define MIPS_Q_DEVICE 1   /* queries pointer is device memory */
 #define MIPS_OUT_DEVICE 2 /* out_scores / out_idx are device memory */
+#define MIPS_OUT_PACKED 4 /* with MIPS_OUT_DEVICE: out_idx receives [nq, k, 2] int64 = {float32 score bits
+                             (zero-extended), index}, the all-gather payload; out_scores is ignored */
 
 /* synthetic data kinds (same functions as oracle/synth.py) */
 #define MIPS_SYNTH_LATTICE 0
@@ -136,6 +138,11 @@ int mips_search(mips_index_t* index, const void* q, int q_dtype, int64_t nq, int
  * last. */
 int mips_merge_topk(const float* cand_s, const int64_t* cand_i, int64_t nq, int parts, int k,
                     int metric, float* out_s, int64_t* out_i, int device, void* hip_stream);
+
+/* The same merge reading the all-gathered MIPS_OUT_PACKED payload as it arrives:
+ * gathered = DEVICE [parts, nq, k, 2] int64 (rank-major). */
+int mips_merge_topk_packed(const int64_t* gathered, int64_t nq, int parts, int k, int metric,
+                           float* out_s, int64_t* out_i, int device, void* hip_stream);
 
 /* In-place row L2 normalisation of a DEVICE float32 matrix [n, d].  Replaces
  * faiss.normalize_L2 behind Mips.l2_normalization (sotasum/mips.py:521-525), used for documents

@@ -10,7 +10,7 @@ fallback.  See DESIGN.md and include/mips_hip.h.
 from . import _lib
 from ._lib import (DTYPE_BF16, DTYPE_F32, MAX_K, METRIC_IP, METRIC_L2, SYNTH_GAUSS, SYNTH_LATTICE,
                    SYNTH_LATTICE_FP8, build)
-from .index import MipsIndex, l2_normalize_, merge_topk, rows_max_sumsq, synth_fill
+from .index import MipsIndex, l2_normalize_, merge_topk, merge_topk_packed, rows_max_sumsq, synth_fill
 from .mips import (KnowledgeBase, Mips, MipsArgs, MipsModelOutput, augment_xb, augment_xq, get_phi,
                    inner_product, retriever_metrics)
 from .sharded import ShardedMipsIndex, pack_topk, shard_bounds, unpack_gathered

@@ -23,7 +23,7 @@ ABI_VERSION = 1
 # constants of include/mips_hip.h
 DTYPE_F32, DTYPE_BF16, DTYPE_FP8_E4M3 = 0, 1, 2
 METRIC_IP, METRIC_L2 = 0, 1
-Q_DEVICE, OUT_DEVICE = 1, 2
+Q_DEVICE, OUT_DEVICE, OUT_PACKED = 1, 2, 4
 SYNTH_LATTICE, SYNTH_GAUSS, SYNTH_LATTICE_FP8 = 0, 1, 2
 MAX_K = 29
 
@@ -86,6 +86,7 @@ def _bind(lib):
         "mips_synth_fill": (i32, [vp, i64, i64, i64, u64, i32, i32, i32, vp]),
         "mips_search": (i32, [vp, vp, i32, i64, i32, vp, vp, i64, i32, vp]),
         "mips_merge_topk": (i32, [vp, vp, i64, i32, i32, i32, vp, vp, i32, vp]),
+        "mips_merge_topk_packed": (i32, [vp, i64, i32, i32, i32, vp, vp, i32, vp]),
         "mips_l2_normalize": (i32, [vp, i64, i64, i32, vp]),
         "mips_rows_max_sumsq": (i32, [vp, i64, i64, c.POINTER(c.c_double), i32, vp]),
         "mips_index_set_param": (i32, [vp, c.c_char_p, i64]),
@@ -103,7 +104,7 @@ EXPORTS = (
     "mips_index_reserve", "mips_index_add", "mips_index_reset", "mips_index_ntotal",
     "mips_index_dim", "mips_index_metric", "mips_index_phi", "mips_index_read_rows",
     "mips_index_add_synthetic", "mips_synth_fill", "mips_search", "mips_merge_topk",
-    "mips_l2_normalize", "mips_rows_max_sumsq", "mips_index_set_param", "mips_scan_timing",
+    "mips_merge_topk_packed", "mips_l2_normalize", "mips_rows_max_sumsq", "mips_index_set_param", "mips_scan_timing",
 )
 
 

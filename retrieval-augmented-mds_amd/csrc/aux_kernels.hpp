@@ -195,6 +195,7 @@ struct MergeArgs {
     int64_t idx_offset;
     float* out_s; // [nq][k]
     int64_t* out_i;
+    int64_t* out_packed; // optional [nq][k][2] = {float bits (zero-extended), global id}: the all-gather payload
 };
 
 // One wave per query.
@@ -297,12 +298,25 @@ __global__ __launch_bounds__(64) void merge_rerank_kernel(MergeArgs p) {
     }
     const int nvalid = __popcll(__ballot(valid));
     if (valid && rank < p.k) {
-        p.out_s[(size_t)q * p.k + rank] = outv;
-        p.out_i[(size_t)q * p.k + rank] = (int64_t)ci + p.idx_offset;
+        const size_t o = (size_t)q * p.k + rank;
+        if (p.out_packed) {
+            p.out_packed[2 * o] = (int64_t)__float_as_uint(outv);
+            p.out_packed[2 * o + 1] = (int64_t)ci + p.idx_offset;
+        } else {
+            p.out_s[o] = outv;
+            p.out_i[o] = (int64_t)ci + p.idx_offset;
+        }
     }
     if (lane < p.k && lane >= nvalid) {
-        p.out_s[(size_t)q * p.k + lane] = p.metric == 1 ? INFINITY : -INFINITY;
-        p.out_i[(size_t)q * p.k + lane] = -1;
+        const size_t o = (size_t)q * p.k + lane;
+        const float pad = p.metric == 1 ? INFINITY : -INFINITY;
+        if (p.out_packed) {
+            p.out_packed[2 * o] = (int64_t)__float_as_uint(pad);
+            p.out_packed[2 * o + 1] = -1;
+        } else {
+            p.out_s[o] = pad;
+            p.out_i[o] = -1;
+        }
     }
 }
 
@@ -330,11 +344,45 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const float* cand_s, con
     }
 }
 
-__global__ void fill_empty_kernel(float* out_s, int64_t* out_i, int64_t total, int metric) {
+// Same merge, reading the all-gathered packed payload directly: gathered [parts][nq][k][2] int64.
+__global__ __launch_bounds__(64) void merge_topk_packed_kernel(const int64_t* gathered, int64_t nq, int parts, int k,
+                                                               int metric, float* out_s, int64_t* out_i) {
+    const int64_t q = blockIdx.x;
+    const int c = parts * k;
+    auto score = [&](int a) {
+        const float f = __uint_as_float((unsigned)gathered[(((size_t)(a / k) * nq + q) * k + a % k) * 2]);
+        return metric == 1 ? -f : f;
+    };
+    auto ident = [&](int a) { return gathered[(((size_t)(a / k) * nq + q) * k + a % k) * 2 + 1]; };
+    for (int a = threadIdx.x; a < c; a += 64) {
+        const float sa = score(a);
+        const int64_t raw = ident(a);
+        const int64_t ia = raw < 0 ? INT64_MAX : raw;
+        int rank = 0;
+        for (int b = 0; b < c; ++b) {
+            const float sb = score(b);
+            const int64_t rb = ident(b);
+            const int64_t ib = rb < 0 ? INT64_MAX : rb;
+            rank += (sb > sa || (sb == sa && (ib < ia || (ib == ia && b < a)))) ? 1 : 0;
+        }
+        if (rank < k) {
+            out_s[(size_t)q * k + rank] = metric == 1 ? -sa : sa;
+            out_i[(size_t)q * k + rank] = raw;
+        }
+    }
+}
+
+__global__ void fill_empty_kernel(float* out_s, int64_t* out_i, int64_t* out_packed, int64_t total, int metric) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t < total) {
-        out_s[t] = metric == 1 ? INFINITY : -INFINITY;
-        out_i[t] = -1;
+        const float pad = metric == 1 ? INFINITY : -INFINITY;
+        if (out_packed) {
+            out_packed[2 * t] = (int64_t)__float_as_uint(pad);
+            out_packed[2 * t + 1] = -1;
+        } else {
+            out_s[t] = pad;
+            out_i[t] = -1;
+        }
     }
 }
 

@@ -179,8 +179,8 @@ int compute_phi(mips_index* ix, hipStream_t st) {
 }
 
 template <int KL>
-int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_out_i, int64_t idx_offset,
-                  hipStream_t st) {
+int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_out_i, int64_t* d_out_packed,
+                  int64_t idx_offset, hipStream_t st) {
     // variant 3 (query-stationary, LDS-DMA) needs the whole K of 32 queries in 192 VGPRs: d padded to 768
     int variant = ix->opt_variant;
     if (variant != 1 && variant != 3) variant = 3;
@@ -283,6 +283,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     m.idx_offset = idx_offset;
     m.out_s = d_out_s;
     m.out_i = d_out_i;
+    m.out_packed = d_out_packed;
     mips::merge_rerank_kernel<KL><<<(int)nq, 64, 0, st>>>(m);
     HIP_TRY(hipGetLastError());
     return MIPS_OK;
@@ -459,11 +460,13 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
     if (k > MIPS_MAX_K) return fail(MIPS_E_UNSUPPORTED, "mips_search: k = %d exceeds MIPS_MAX_K = %d", k, MIPS_MAX_K);
     if (q_dtype != MIPS_DTYPE_F32 && q_dtype != MIPS_DTYPE_BF16) return fail(MIPS_E_INVALID, "mips_search: q_dtype must be F32 or BF16");
     if (nq == 0 || k == 0) return MIPS_OK;
-    if (!q || !out_scores || !out_idx) return fail(MIPS_E_INVALID, "mips_search: NULL buffer");
+    if (!q || !out_idx || (!out_scores && !(flags & MIPS_OUT_PACKED))) return fail(MIPS_E_INVALID, "mips_search: NULL buffer");
     if (nq > (1 << 24)) return fail(MIPS_E_UNSUPPORTED, "mips_search: more than 2^24 queries in one call");
     DeviceGuard g(ix->device);
     hipStream_t st = (hipStream_t)hip_stream;
     const bool out_dev = (flags & MIPS_OUT_DEVICE) != 0;
+    const bool packed = (flags & MIPS_OUT_PACKED) != 0;
+    if (packed && !out_dev) return fail(MIPS_E_INVALID, "mips_search: MIPS_OUT_PACKED requires MIPS_OUT_DEVICE");
 
     float* d_s = out_scores;
     int64_t* d_i = out_idx;
@@ -478,7 +481,7 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
 
     if (ix->ntotal == 0) {
         const int64_t total = nq * k;
-        mips::fill_empty_kernel<<<(int)((total + 255) / 256), 256, 0, st>>>(d_s, d_i, total, ix->metric);
+        mips::fill_empty_kernel<<<(int)((total + 255) / 256), 256, 0, st>>>(d_s, d_i, packed ? d_i : nullptr, total, ix->metric);
         HIP_TRY(hipGetLastError());
     } else {
         if (ix->metric == MIPS_METRIC_L2) {
@@ -497,11 +500,11 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
             HIP_TRY(hipGetLastError());
         }
         if (k <= 5)
-            rc = launch_search<8>(ix, nq, k, d_s, d_i, idx_offset, st);
+            rc = launch_search<8>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st);
         else if (k <= 13)
-            rc = launch_search<16>(ix, nq, k, d_s, d_i, idx_offset, st);
+            rc = launch_search<16>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st);
         else
-            rc = launch_search<32>(ix, nq, k, d_s, d_i, idx_offset, st);
+            rc = launch_search<32>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st);
         if (rc) return rc;
     }
     if (!out_dev) {
@@ -521,6 +524,19 @@ int mips_merge_topk(const float* cand_s, const int64_t* cand_i, int64_t nq, int 
     DeviceGuard g(device);
     if (!g.ok) return fail(MIPS_E_HIP, "hipSetDevice(%d) failed", device);
     mips::merge_topk_kernel<<<(int)nq, 64, 0, (hipStream_t)hip_stream>>>(cand_s, cand_i, parts * k, k, metric, out_s, out_i);
+    HIP_TRY(hipGetLastError());
+    return MIPS_OK;
+}
+
+int mips_merge_topk_packed(const int64_t* gathered, int64_t nq, int parts, int k, int metric, float* out_s,
+                           int64_t* out_i, int device, void* hip_stream) {
+    if (nq < 0 || parts <= 0 || k < 0) return fail(MIPS_E_INVALID, "mips_merge_topk_packed: bad sizes");
+    if (nq == 0 || k == 0) return MIPS_OK;
+    if (!gathered || !out_s || !out_i) return fail(MIPS_E_INVALID, "mips_merge_topk_packed: NULL buffer");
+    if ((int64_t)parts * k > 65536) return fail(MIPS_E_UNSUPPORTED, "mips_merge_topk_packed: parts * k too large");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(MIPS_E_HIP, "hipSetDevice(%d) failed", device);
+    mips::merge_topk_packed_kernel<<<(int)nq, 64, 0, (hipStream_t)hip_stream>>>(gathered, nq, parts, k, metric, out_s, out_i);
     HIP_TRY(hipGetLastError());
     return MIPS_OK;
 }

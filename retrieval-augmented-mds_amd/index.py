@@ -166,6 +166,25 @@ class MipsIndex:
         del keep
         return D, I
 
+    def search_packed(self, x, k: int, idx_offset: int = 0):
+        """Device-only search returning the all-gather payload: CUDA int64 [nq, k, 2] =
+        {float32 score bits, index + idx_offset} (sharded.py)."""
+        import torch
+
+        k = int(k)
+        if k > _lib.MAX_K:
+            raise NotImplementedError(f"k = {k} > {_lib.MAX_K} is not supported by this build")
+        ptr, code, is_dev, nq, keep = self._as_buffer(x, "search")
+        if not is_dev:
+            raise ValueError("search_packed needs a CUDA tensor")
+        out = torch.empty((nq, k, 2), dtype=torch.int64, device=f"cuda:{self.device}")
+        with self._mutex:
+            _lib.check(self._lib.mips_search(self._h, ptr, code, nq, k, None, out.data_ptr(), int(idx_offset),
+                                             _lib.Q_DEVICE | _lib.OUT_DEVICE | _lib.OUT_PACKED,
+                                             _stream_handle(self.device)), "mips_search")
+        del keep
+        return out
+
     def set_param(self, name: str, value: int) -> None:
         """Launch tuning knob ("nsplit", "qgroups"); never changes results."""
         _lib.check(self._lib.mips_index_set_param(self._h, name.encode(), int(value)), "mips_index_set_param")
@@ -262,6 +281,19 @@ def rows_max_sumsq(x) -> float:
     _lib.check(lib.mips_rows_max_sumsq(x.data_ptr(), x.shape[0], x.shape[1], ctypes.byref(out), x.device.index,
                                        _stream_handle(x.device.index)), "mips_rows_max_sumsq")
     return out.value
+
+
+def merge_topk_packed(gathered, nq: int, parts: int, k: int, metric: int = _lib.METRIC_IP):
+    """Device merge straight from the gathered payload: CUDA int64 [parts * nq, k, 2] (rank-major)."""
+    import torch
+
+    lib = _lib.load()
+    dev = gathered.device.index
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=gathered.device)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=gathered.device)
+    _lib.check(lib.mips_merge_topk_packed(gathered.data_ptr(), nq, parts, k, metric, out_s.data_ptr(), out_i.data_ptr(),
+                                          dev, _stream_handle(dev)), "mips_merge_topk_packed")
+    return out_s, out_i
 
 
 def merge_topk(cand_s, cand_i, parts: int, k: int, metric: int = _lib.METRIC_IP):

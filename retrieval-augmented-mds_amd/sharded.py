@@ -69,6 +69,7 @@ class ShardedMipsIndex:
 
             self.local = MipsIndex(d, metric=metric, dtype=dtype, device=device)
             local_search = self.local.search
+        self._fast = self.local is not None and merge is None  # both device steps are the library's own
         if merge is None:
             from .index import merge_topk as merge
         self._local_search = local_search
@@ -103,13 +104,27 @@ class ShardedMipsIndex:
         import torch
         import torch.distributed as dist
 
+        backend = dist.get_backend(self.group) if self.world > 1 else None
+        if (self.world > 1 and self.local is not None and self._fast and isinstance(q, torch.Tensor) and q.is_cuda):
+            # device fast path: the re-score kernel writes the all-gather payload, the merge kernel reads
+            # the gathered buffer as it arrives -- no tensor reshuffling between scan and collective
+            from .index import merge_topk_packed
+
+            packed = self.local.search_packed(q, k, self.lo)
+            nq = packed.shape[0]
+            if backend == "gloo":
+                packed = packed.cpu()
+            gathered = torch.empty((self.world * nq, k, 2), dtype=torch.int64, device=packed.device)
+            dist.all_gather_into_tensor(gathered, packed, group=self.group)  # the ONE collective of the path
+            if not gathered.is_cuda:
+                gathered = gathered.to(q.device)
+            return merge_topk_packed(gathered, nq, self.world, k, self.metric_type)
         s, i = self._local_search(q, k, self.lo)
         if self.world == 1:
             return s, i
         as_numpy = not isinstance(s, torch.Tensor)
         if as_numpy:
             s, i = torch.from_numpy(np.ascontiguousarray(s)), torch.from_numpy(np.ascontiguousarray(i))
-        backend = dist.get_backend(self.group)
         home = s.device
         if backend == "nccl" and not s.is_cuda:
             home = torch.device(f"cuda:{self.local.device}" if self.local is not None else "cuda")

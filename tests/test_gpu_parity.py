@@ -361,3 +361,22 @@ def test_sharded_index_multi_rank_on_one_gpu(world):
     ret = mp.Manager().dict()
     mp.spawn(_rank_worker, args=(world, port, 50001, 200, 768, 5, ret), nprocs=world, join=True)
     assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_packed_payload_roundtrip():
+    x = synth.generate(81, 0, 9001, 768, synth.KIND_LATTICE)
+    q = torch.from_numpy(synth.generate(82, 0, 77, 768, synth.KIND_LATTICE)).cuda()
+    k = 5
+    full_s, full_i = _index(x).search(q, k)
+    parts = []
+    for r in range(3):
+        lo, hi = ram.shard_bounds(9001, 3, r)
+        p = _index(x[lo:hi]).search_packed(q, k, lo)
+        assert p.shape == (77, k, 2) and p.dtype == torch.int64
+        s_, i_ = _index(x[lo:hi]).search(q, k, lo)
+        assert torch.equal(p[..., 1], i_) and torch.equal(p[..., 0].to(torch.int32).view(torch.float32), s_)
+        parts.append(p)
+    ms, mi = ram.merge_topk_packed(torch.cat(parts, dim=0), 77, 3, k)
+    assert torch.equal(mi, full_i) and torch.equal(ms, full_s)
+    empty = ram.MipsIndex(768).search_packed(q, k)
+    assert (empty[..., 1] == -1).all()
