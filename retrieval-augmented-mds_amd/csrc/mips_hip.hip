@@ -181,12 +181,15 @@ int compute_phi(mips_index* ix, hipStream_t st) {
 template <int KL>
 int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_out_i, int64_t* d_out_packed,
                   int64_t idx_offset, hipStream_t st) {
-    // variant 3 (query-stationary, LDS-DMA) needs the whole K of 32 queries in 192 VGPRs: d padded to 768
+    // variant 3 (query-stationary, LDS-DMA): the whole K of a wave's 32 queries lives in its VGPRs, so it
+    // exists for a few row lengths only: 256 / 512 / 768 (8 waves, 2 per SIMD) and 1024 (4 waves, 1 per SIMD)
     int variant = ix->opt_variant;
     if (variant != 1 && variant != 3) variant = 3;
-    if (ix->ld != 768 || KL != 8) variant = 1; // v3 register budget: 192 fragment + 16 list VGPRs of 256
+    const bool v3_dim = ix->ld == 256 || ix->ld == 512 || ix->ld == 768 || ix->ld == 1024;
+    if (!v3_dim || KL != 8) variant = 1; // K' > 8 lists do not fit the register budget next to the fragments
+    const int v3_waves = ix->ld == 1024 ? 4 : 8;
     const int tm = variant == 1 ? mips::TM : mips::V3_DB;             // documents per scheduling unit ("tile")
-    const int tn = variant == 1 ? mips::TN : mips::V3_TN;             // queries per workgroup
+    const int tn = variant == 1 ? mips::TN : v3_waves * 32;           // queries per workgroup
     const int lists = 2;                                              // running lists per (query, split)
     const int wg_target = variant == 1 ? 512 : 256;                   // resident workgroups on 256 CUs
     const int64_t nq_pad = round_up(nq, kQueryAlign);
@@ -244,23 +247,24 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         HIP_TRY(hipEventRecord(ix->ev0[slot], st));
         mips::scan_kernel<KL><<<grid, mips::SCAN_THREADS, mips::SCAN_LDS_BYTES, st>>>(a);
     } else if constexpr (KL == 8) {
-        constexpr int KS16 = 48;
-        constexpr int lds = mips::V3_STAGES * mips::V3_DB * KS16 * 32 + 8 * 64 * 4; // ring + threshold slots
-        const int sub = ix->opt_sub; // experiment selector: 0 = 8 waves x 32 queries, 1 = 4 waves x 64 queries
+        const int lds = (v3_waves == 4 ? 2 : 3) * mips::V3_DB * ix->ld * 2 + v3_waves * 256; // ring + threshold slots
+        const int sub = ix->opt_sub; // A/B selector for tools_ab.py (0 = shipped configuration)
         auto go = [&](auto kern, int threads) -> int {
             HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             HIP_TRY(hipEventRecord(ix->ev0[slot], st));
             kern<<<grid, threads, lds, st>>>(a);
             return MIPS_OK;
         };
-        int rc2;   // sub: A/B selector for tools_ab.py (0 = shipped configuration)
-        if (sub == 1) rc2 = go(mips::scan_kernel_v3<KL, KS16, 2, 6, true, 0, false>, 256);       // 4 waves x 64 queries
-        else if (sub == 2) rc2 = go(mips::scan_kernel_v3<KL, KS16, 1, 2, false>, 512);            // DMA issued in one burst
-        else if (sub == 4) rc2 = go(mips::scan_kernel_v3<KL, KS16, 1, 2, true, 0, false>, 512);   // no shared thresholds
-        else if (sub == 5) rc2 = go(mips::scan_kernel_v3<KL, KS16, 1, 3, true>, 512);             // prefetch depth 3
-        else if (sub == 8) rc2 = go(mips::scan_kernel_v3<KL, KS16, 1, 2, true, 1>, 512);          // timing only: no epilogue
-        else if (sub == 9) rc2 = go(mips::scan_kernel_v3<KL, KS16, 1, 2, true, 2>, 512);          // timing only: pre-test only
-        else rc2 = go(mips::scan_kernel_v3<KL, KS16, 1, 2, true>, 512);
+        int rc2;
+        if (ix->ld == 1024) rc2 = go(mips::scan_kernel_v3<KL, 64, 1, 4, false, 0, true, 4, 2>, 256);
+        else if (ix->ld == 512) rc2 = go(mips::scan_kernel_v3<KL, 32, 1, 2, true>, 512);
+        else if (ix->ld == 256) rc2 = go(mips::scan_kernel_v3<KL, 16, 1, 2, true>, 512);
+        else if (sub == 2) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, false>, 512);            // DMA issued in one burst
+        else if (sub == 4) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, false>, 512);   // no shared thresholds
+        else if (sub == 5) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 3, true>, 512);             // prefetch depth 3
+        else if (sub == 8) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 1>, 512);          // timing only: no epilogue
+        else if (sub == 9) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 2>, 512);          // timing only: pre-test only
+        else rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true>, 512);
         if (rc2) return rc2;
     } else {
         return fail(MIPS_E_UNSUPPORTED, "internal: scan variant 3 requires K' = 8");

@@ -28,16 +28,12 @@
 
 namespace mips {
 
-constexpr int V3_TN = 256;     // queries per workgroup
-constexpr int V3_DB = 32;      // documents per block
-constexpr int V3_STAGES = 3;
-// NQB = 32-query blocks per wave: 1 -> 8 waves x 32 queries, two waves per SIMD (256 registers each);
-//                                 2 -> 4 waves x 64 queries, one wave per SIMD (512 registers).
-template <int NQB> struct V3Cfg {
-    static constexpr int WAVES = 8 / NQB;
-    static constexpr int THREADS = 64 * WAVES;
-};
-
+constexpr int V3_DB = 32; // documents per block
+// Configurations (queries per workgroup = WAVES * NQB * 32):
+//   d <= 768 : WAVES = 8, NQB = 1, STAGES = 3  -- two waves per SIMD, 256 registers each (192 fragment VGPRs at d = 768)
+//   d = 1024 : WAVES = 4, NQB = 1, STAGES = 2  -- one wave per SIMD with the 512-register file (256 fragment VGPRs),
+//                                                 64 KiB blocks, so only two ring stages fit the 160 KiB LDS
+//   (WAVES = 4, NQB = 2 is the 64-queries-per-wave experiment of profiles/r1_v3_query_stationary.)
 // inline asm is device-only: the host pass parses kernel bodies too and must not see GPU constraints
 __device__ __forceinline__ void keep_alive(const f32x16& v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -70,9 +66,10 @@ __device__ __forceinline__ void publish_umax(unsigned key, unsigned voff, __amdg
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
-template <int KL, int KS16, int NQB, int AD, bool DMA_SPREAD, int TIMING_MODE = 0, bool GLOBAL_THR = true>
-__global__ __launch_bounds__(V3Cfg<NQB>::THREADS, NQB == 1 ? 2 : 1) void scan_kernel_v3(ScanArgs p) {
-    constexpr int WAVES = V3Cfg<NQB>::WAVES;
+template <int KL, int KS16, int NQB, int AD, bool DMA_SPREAD, int TIMING_MODE = 0, bool GLOBAL_THR = true,
+          int WAVES = 8 / NQB, int STAGES = 3>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs p) {
+    constexpr int V3_TN = WAVES * NQB * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int STAGE_BYTES = V3_DB * KS16 * 32; // 32 rows x (KS16 * 16) k x 2 B
     constexpr int PIECES = KS16;                   // 1 KiB pieces per block
@@ -106,12 +103,12 @@ __global__ __launch_bounds__(V3Cfg<NQB>::THREADS, NQB == 1 ? 2 : 1) void scan_ke
         // Consume the fragments here: the compiler's wait for these ordinary loads then sits BEFORE the
         // pipeline instead of inside the loop (where a vmcnt(0) would drain the LDS-DMA queue every
         // block), and the values stay opaque register residents.
-        // (NQB == 2: 384 fragment registers exceed the 256 architectural VGPRs; the first 256 are pinned
+        // (One wave per SIMD: the fragments exceed or crowd the 256 architectural VGPRs; part of them is pinned
         // in the accumulation half of the unified file -- MFMA reads B operands from AGPRs directly --
         // otherwise hipcc treats AGPRs as spill space and copies 4 registers back before every MFMA.)
 #pragma unroll
         for (int s = 0; s < KS16; ++s) {
-            if (NQB == 2 && (n * KS16 + s) * 4 < 256) asm volatile("" : "+a"(bq[n][s]));
+            if (WAVES == 4 && (n * KS16 + s) < (NQB == 2 ? 64 : KS16 / 2)) asm volatile("" : "+a"(bq[n][s]));
             else asm volatile("" : "+v"(bq[n][s]));
         }
     }
@@ -146,7 +143,7 @@ __global__ __launch_bounds__(V3Cfg<NQB>::THREADS, NQB == 1 ? 2 : 1) void scan_ke
     // 64 slots are contiguous: one buffer_load_dword ... lds refreshes them.  thr_addr is this lane's
     // slot in the LDS threshold area and, with the descriptor base shifted by the area offset, also the
     // DMA's voffset -- one persistent VGPR for both.
-    constexpr unsigned THR_AREA = V3_STAGES * STAGE_BYTES;
+    constexpr unsigned THR_AREA = STAGES * STAGE_BYTES;
     const unsigned thr_addr = THR_AREA + wave * 256 + lane * 4;
     __amdgpu_buffer_rsrc_t thr_rsrc;
     if (GLOBAL_THR) {
@@ -187,6 +184,11 @@ __global__ __launch_bounds__(V3Cfg<NQB>::THREADS, NQB == 1 ? 2 : 1) void scan_ke
     const int rd_row = l31 * 128;
     const int rd_swz = (l31 >> 1) & 7;
 
+    // one 256-byte LDS-DMA (sc1: served by L2, not by this CU's L1) re-reads the wave's 64 threshold slots
+    auto refresh_thresholds = [&]() {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rsrc, (lds_void*)(smem + THR_AREA + wave * 256), 4, thr_addr, 0, 0, 16);
+    };
+
     // scores block `blk` (ring stage `stage`); when pblk >= 0 the DMA pieces of block pblk are issued
     // one at a time between the MFMAs (spread over the chain: the partner wave keeps the matrix pipe busy
     // during an issue, which right after the barrier it could not, both waves being there together)
@@ -206,9 +208,7 @@ __global__ __launch_bounds__(V3Cfg<NQB>::THREADS, NQB == 1 ? 2 : 1) void scan_ke
         bf16x8 ar[AD];
 #pragma unroll
         for (int s = 0; s < AD; ++s) ar[s] = lds_frag(s);
-        if (GLOBAL_THR && NQB == 1) { // first VMEM op of the block: covered by the next block's counted wait
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rsrc, (lds_void*)(smem + THR_AREA + wave * 256), 4, thr_addr, 0, 0, 16);
-        }
+        if (GLOBAL_THR && NQB == 1) refresh_thresholds(); // first VMEM op of the block
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KS16; ++s) {
@@ -262,27 +262,37 @@ __global__ __launch_bounds__(V3Cfg<NQB>::THREADS, NQB == 1 ? 2 : 1) void scan_ke
         }
     };
 
-    // Block i lives in ring stage i % 3 and is issued two blocks ahead.  The issue is unconditional:
-    // past the end of the split the LAST block is fetched again into a stage nobody reads any more, which
-    // keeps the MFMA chain free of branches and the vmcnt arithmetic uniform.
+    // Block i lives in ring stage i % STAGES and is issued STAGES - 1 blocks ahead.  The issue is
+    // unconditional: past the end of the split the LAST block is fetched again into a stage nobody reads any
+    // more, which keeps the MFMA chain free of branches and the vmcnt arithmetic uniform.
     const unsigned char* first = docs_b + (int64_t)b0 * V3_DB * row_bytes;
     const unsigned char* last = docs_b + (int64_t)(b1 - 1) * V3_DB * row_bytes;
     const int64_t blk_bytes = V3_DB * row_bytes;
+    constexpr int AHEAD = STAGES - 1;
     if (nb > 0) {
-        issue(first, 0);
-        issue(nb > 1 ? first + blk_bytes : last, 1);
+        // The prologue issues exactly what AHEAD steady-state blocks would (threshold refresh, then the
+        // pieces), so that "everything but the (STAGES - 2) * PER_BLOCK youngest operations has landed"
+        // means the same at block 0 as later.  (Leaving the refresh out here made vmcnt one too lax for
+        // the first block: a cold-start race caught by test_mips_facade_end_to_end.)
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a) {
+            if (GLOBAL_THR && NQB == 1) refresh_thresholds();
+            issue(a < nb ? first + a * blk_bytes : last, a);
+        }
     }
-    const unsigned char* pbase = nb > 2 ? first + 2 * blk_bytes : last;
-    int stage = 0, pstage = 2;
+    const unsigned char* pbase = nb > AHEAD ? first + AHEAD * blk_bytes : last;
+    int stage = 0, pstage = AHEAD;
+    // VMEM operations a wave issues per block: its DMA pieces and the threshold refresh; at the top of
+    // block i everything older than the (STAGES - 2) youngest blocks' worth must have landed
+    constexpr int PER_BLOCK = PPW + ((GLOBAL_THR && NQB == 1) ? 1 : 0);
     for (int i = 0; i < nb; ++i) {
-        // this wave's pieces of block i have landed once at most block i+1's remain in flight
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + ((GLOBAL_THR && NQB == 1) ? 1 : 0)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_BLOCK) : "memory");
         __builtin_amdgcn_s_barrier(); // all shares of block i landed; everyone is done with block i-1
         if (!DMA_SPREAD) issue(pbase, pstage);
         block(b0 + i, stage, pbase, pstage);
-        if (i + 3 < nb) pbase += blk_bytes; // stops at the last block
-        stage = stage == 2 ? 0 : stage + 1;
-        pstage = pstage == 2 ? 0 : pstage + 1;
+        if (i + AHEAD + 1 < nb) pbase += blk_bytes; // stops at the last block
+        stage = stage == STAGES - 1 ? 0 : stage + 1;
+        pstage = pstage == STAGES - 1 ? 0 : pstage + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no DMA may outlive the workgroup's LDS allocation
 

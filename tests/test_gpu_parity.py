@@ -102,7 +102,10 @@ def test_cfg1_matches_reference_golden(golden_dir):
 
 
 @pytest.mark.parametrize("n,nq,d,k", [(100003, 257, 768, 5), (4099, 129, 1024, 10), (777, 5, 100, 1),
-                                       (20000, 130, 769, 16), (131, 3, 64, 13), (128, 128, 64, 6)])
+                                       (20000, 130, 769, 16), (131, 3, 64, 13), (128, 128, 64, 6),
+                                       # query-stationary kernel configurations: d = 1024 (4 waves), 512, 256, padded 500
+                                       (70001, 300, 1024, 5), (33, 1, 1024, 3), (50000, 513, 512, 5),
+                                       (9000, 40, 256, 4), (12345, 70, 500, 5)])
 def test_ragged_shapes_gauss(n, nq, d, k):
     x = synth.generate(21, 0, n, d, synth.KIND_GAUSS)
     q = synth.generate(22, 0, nq, d, synth.KIND_GAUSS)
@@ -380,3 +383,21 @@ def test_packed_payload_roundtrip():
     assert torch.equal(mi, full_i) and torch.equal(ms, full_s)
     empty = ram.MipsIndex(768).search_packed(q, k)
     assert (empty[..., 1] == -1).all()
+
+
+def test_tiny_splits_cold_start_stress():
+    """Few blocks per workgroup and hundreds of workgroups starting together: the first block of every
+    split is consumed right after the prologue's DMA.  Repeated with cache-evicting traffic in between."""
+    rng = np.random.default_rng(5)
+    for n, nq, d in ((10000, 8, 768), (313 * 32, 300, 768), (7000, 3, 1024), (9000, 40, 512)):
+        x = synth.generate(91, 0, n, d, synth.KIND_GAUSS)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)            # small scores, many negative
+        q = synth.generate(92, 0, nq, d, synth.KIND_GAUSS)
+        ix = _index(x)
+        stored = synth.bf16_bits_to_f32(ix.rows_bf16())
+        es, ei = orc.search_exact(q, stored, 5)
+        junk = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+        for _ in range(12):
+            junk.random_(0, 255)                                   # 256 MiB of writes: evicts L2 / Infinity Cache
+            s, i = ix.search(q, 5)
+            assert np.array_equal(i, ei) and np.array_equal(s, es)
