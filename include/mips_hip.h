@@ -144,6 +144,18 @@ int mips_merge_topk(const float* cand_s, const int64_t* cand_i, int64_t nq, int 
 int mips_merge_topk_packed(const int64_t* gathered, int64_t nq, int parts, int k, int metric,
                            float* out_s, int64_t* out_i, int device, void* hip_stream);
 
+/* The ignore filter of Mips.search (sotasum/mips.py:388-398) on the device: from k_fetched (= k + 1)
+ * hits per query drop every hit whose id equals ignore[q] and keep the first k.  All DEVICE buffers:
+ * scores/idx [nq, k_fetched], ignore [nq] int64, out_s/out_i [nq, k]. */
+int mips_filter_ignore(const float* scores, const int64_t* idx, const int64_t* ignore, int64_t nq,
+                       int k_fetched, int k, float* out_s, int64_t* out_i, int device, void* hip_stream);
+
+/* Cosine re-score of the retriever scoring hook (sotasum/retriever_generator.py:158-172):
+ * out[b][j] = q_b . c_bj / (|q_b| |c_bj|).  DEVICE buffers: query [b, d], cls [b, k, d] of dtype
+ * (MIPS_DTYPE_F32 or MIPS_DTYPE_BF16), out [b, k] float32 (fp32 accumulation). */
+int mips_cosine_rescore(const void* query, const void* cls, int dtype, int64_t b, int k, int64_t d,
+                        float* out, int device, void* hip_stream);
+
 /* In-place row L2 normalisation of a DEVICE float32 matrix [n, d].  Replaces
  * faiss.normalize_L2 behind Mips.l2_normalization (sotasum/mips.py:521-525), used for documents
  * at build time (mips.py:306-314, 358-361) and for queries (mips.py:369-370).  Rows of norm 0 are

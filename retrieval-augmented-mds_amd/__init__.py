@@ -10,7 +10,8 @@ fallback.  See DESIGN.md and include/mips_hip.h.
 from . import _lib
 from ._lib import (DTYPE_BF16, DTYPE_F32, MAX_K, METRIC_IP, METRIC_L2, SYNTH_GAUSS, SYNTH_LATTICE,
                    SYNTH_LATTICE_FP8, build)
-from .index import MipsIndex, l2_normalize_, merge_topk, merge_topk_packed, rows_max_sumsq, synth_fill
+from .index import (MipsIndex, cosine_rescore, filter_ignore, l2_normalize_, merge_topk, merge_topk_packed,
+                    rows_max_sumsq, synth_fill)
 from .mips import (KnowledgeBase, Mips, MipsArgs, MipsModelOutput, augment_xb, augment_xq, get_phi,
                    inner_product, retriever_metrics)
 from .sharded import ShardedMipsIndex, pack_topk, shard_bounds, unpack_gathered
@@ -18,6 +19,6 @@ from .sharded import ShardedMipsIndex, pack_topk, shard_bounds, unpack_gathered
 __all__ = [
     "MipsIndex", "ShardedMipsIndex", "Mips", "MipsArgs", "MipsModelOutput", "KnowledgeBase",
     "get_phi", "augment_xb", "augment_xq", "inner_product", "retriever_metrics",
-    "l2_normalize_", "rows_max_sumsq", "merge_topk", "synth_fill", "shard_bounds", "pack_topk",
+    "l2_normalize_", "rows_max_sumsq", "merge_topk", "merge_topk_packed", "filter_ignore", "cosine_rescore", "synth_fill", "shard_bounds", "pack_topk",
     "unpack_gathered", "build", "METRIC_IP", "METRIC_L2", "MAX_K",
 ]

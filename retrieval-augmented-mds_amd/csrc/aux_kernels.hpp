@@ -372,6 +372,59 @@ __global__ __launch_bounds__(64) void merge_topk_packed_kernel(const int64_t* ga
     }
 }
 
+// ------------------------------------------------------------------ ignore filter of Mips.search on the device
+// sotasum/mips.py:388-398: k + 1 hits were fetched; per query drop every hit whose id equals ignore[q] and
+// keep the first k of the rest.  One thread per query (k1 <= 30).
+__global__ void filter_ignore_kernel(const float* s, const int64_t* id, const int64_t* ignore, int64_t nq, int k1, int k,
+                                     float* out_s, int64_t* out_i) {
+    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const int64_t banned = ignore[q];
+    int w = 0;
+    for (int t = 0; t < k1 && w < k; ++t) {
+        const int64_t v = id[q * k1 + t];
+        if (v != banned) {
+            out_s[q * k + w] = s[q * k1 + t];
+            out_i[q * k + w] = v;
+            ++w;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ cosine re-score of the scoring hook
+// sotasum/retriever_generator.py:158-172: scores[b][j] = q_b . c_bj / (|q_b| |c_bj|).  One wave per (b, j);
+// fp32 accumulation.  T = float or bf16 bits (uint16_t).
+template <typename T>
+__device__ __forceinline__ float load_as_f32(const T* p, int64_t i);
+template <>
+__device__ __forceinline__ float load_as_f32<float>(const float* p, int64_t i) { return p[i]; }
+template <>
+__device__ __forceinline__ float load_as_f32<uint16_t>(const uint16_t* p, int64_t i) { return bf16_bits_to_f32(p[i]); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void cosine_rescore_kernel(const T* query, const T* cls, int64_t pairs, int k, int d,
+                                                             float* out) {
+    const int64_t pr = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (pr >= pairs) return;
+    const T* q = query + (pr / k) * d;
+    const T* c = cls + pr * d;
+    float qc = 0.f, qq = 0.f, cc = 0.f;
+    for (int t = lane; t < d; t += 64) {
+        const float a = load_as_f32<T>(q, t), b = load_as_f32<T>(c, t);
+        qc += a * b;
+        qq += a * a;
+        cc += b * b;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        qc += __shfl_xor(qc, off);
+        qq += __shfl_xor(qq, off);
+        cc += __shfl_xor(cc, off);
+    }
+    if (lane == 0) out[pr] = qc / (sqrtf(qq) * sqrtf(cc));
+}
+
 __global__ void fill_empty_kernel(float* out_s, int64_t* out_i, int64_t* out_packed, int64_t total, int metric) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t < total) {

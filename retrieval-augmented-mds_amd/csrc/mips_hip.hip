@@ -545,6 +545,37 @@ int mips_merge_topk_packed(const int64_t* gathered, int64_t nq, int parts, int k
     return MIPS_OK;
 }
 
+int mips_filter_ignore(const float* scores, const int64_t* idx, const int64_t* ignore, int64_t nq, int k_fetched, int k,
+                       float* out_s, int64_t* out_i, int device, void* hip_stream) {
+    if (nq < 0 || k < 0 || k_fetched < k) return fail(MIPS_E_INVALID, "mips_filter_ignore: bad sizes");
+    if (nq == 0 || k == 0) return MIPS_OK;
+    if (!scores || !idx || !ignore || !out_s || !out_i) return fail(MIPS_E_INVALID, "mips_filter_ignore: NULL buffer");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(MIPS_E_HIP, "hipSetDevice(%d) failed", device);
+    mips::filter_ignore_kernel<<<(int)((nq + 255) / 256), 256, 0, (hipStream_t)hip_stream>>>(scores, idx, ignore, nq, k_fetched,
+                                                                                          k, out_s, out_i);
+    HIP_TRY(hipGetLastError());
+    return MIPS_OK;
+}
+
+int mips_cosine_rescore(const void* query, const void* cls, int dtype, int64_t b, int k, int64_t d, float* out, int device,
+                        void* hip_stream) {
+    if (b < 0 || k < 0 || d <= 0) return fail(MIPS_E_INVALID, "mips_cosine_rescore: bad sizes");
+    if (dtype != MIPS_DTYPE_F32 && dtype != MIPS_DTYPE_BF16) return fail(MIPS_E_INVALID, "mips_cosine_rescore: dtype must be F32 or BF16");
+    if (b == 0 || k == 0) return MIPS_OK;
+    if (!query || !cls || !out) return fail(MIPS_E_INVALID, "mips_cosine_rescore: NULL buffer");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(MIPS_E_HIP, "hipSetDevice(%d) failed", device);
+    const int64_t pairs = b * k;
+    const int grid = (int)((pairs + 3) / 4);
+    if (dtype == MIPS_DTYPE_F32)
+        mips::cosine_rescore_kernel<float><<<grid, 256, 0, (hipStream_t)hip_stream>>>((const float*)query, (const float*)cls, pairs, k, (int)d, out);
+    else
+        mips::cosine_rescore_kernel<uint16_t><<<grid, 256, 0, (hipStream_t)hip_stream>>>((const uint16_t*)query, (const uint16_t*)cls, pairs, k, (int)d, out);
+    HIP_TRY(hipGetLastError());
+    return MIPS_OK;
+}
+
 int mips_l2_normalize(float* x_device, int64_t n, int64_t d, int device, void* hip_stream) {
     if (n < 0 || d <= 0 || (n > 0 && !x_device)) return fail(MIPS_E_INVALID, "mips_l2_normalize: bad argument");
     if (n == 0) return MIPS_OK;

@@ -312,3 +312,45 @@ def merge_topk(cand_s, cand_i, parts: int, k: int, metric: int = _lib.METRIC_IP)
     _lib.check(lib.mips_merge_topk(cand_s.data_ptr(), cand_i.data_ptr(), nq, parts, k, metric, out_s.data_ptr(),
                                    out_i.data_ptr(), dev, _stream_handle(dev)), "mips_merge_topk")
     return out_s, out_i
+
+
+def filter_ignore(scores, idx, ignore, k: int):
+    """Device form of the ignore filter of sotasum/mips.py:388-398: CUDA scores/idx [nq, k+1] and
+    ignore [nq] -> ([nq, k], [nq, k])."""
+    import torch
+
+    lib = _lib.load()
+    nq, k1 = scores.shape
+    dev = scores.device.index
+    scores, idx = scores.contiguous(), idx.contiguous()
+    ignore = torch.as_tensor(ignore, device=scores.device, dtype=torch.int64).contiguous()
+    if ignore.shape != (nq,):
+        raise ValueError(f"ignore_indexes: expected {nq} ids, got {tuple(ignore.shape)}")
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=scores.device)
+    _lib.check(lib.mips_filter_ignore(scores.data_ptr(), idx.data_ptr(), ignore.data_ptr(), nq, k1, k, out_s.data_ptr(),
+                                      out_i.data_ptr(), dev, _stream_handle(dev)), "mips_filter_ignore")
+    return out_s, out_i
+
+
+def cosine_rescore(query, mips_cls):
+    """retriever_generator.py:158-172 on the device: query [B, 1, d] or [B, d], mips_cls [B, k, d]
+    (CUDA float32 or bfloat16) -> float32 [B, k] = q . c / (|q| |c|)."""
+    import torch
+
+    lib = _lib.load()
+    if query.dim() == 3:
+        query = query[:, 0, :]
+    b, k, d = mips_cls.shape
+    if query.shape != (b, d) or not (query.is_cuda and mips_cls.is_cuda):
+        raise ValueError("cosine_rescore: expected CUDA query [B,(1,)d] and mips_cls [B,k,d]")
+    if mips_cls.dtype == torch.bfloat16 and query.dtype == torch.bfloat16:
+        code = _lib.DTYPE_BF16
+    else:
+        query, mips_cls, code = query.float(), mips_cls.float(), _lib.DTYPE_F32
+    query, mips_cls = query.contiguous(), mips_cls.contiguous()
+    dev = query.device.index
+    out = torch.empty((b, k), dtype=torch.float32, device=query.device)
+    _lib.check(lib.mips_cosine_rescore(query.data_ptr(), mips_cls.data_ptr(), code, b, k, d, out.data_ptr(), dev,
+                                       _stream_handle(dev)), "mips_cosine_rescore")
+    return out

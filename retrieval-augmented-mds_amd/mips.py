@@ -300,6 +300,28 @@ class Mips:
             scores, indices = out_s, out_i
         return scores, indices
 
+    def search_device(self, queries, ignore_indexes=None, k: int = 10, prepare: bool = True):
+        """Device-resident form of `_prepare_query` + `search`: takes the query CLS
+        vectors as a CUDA tensor [B, d] straight from the encoder -- removing the
+        `.detach().cpu().float().numpy()` hop of retriever_generator.py:143 -- normalises them on the
+        device when the reference would (mips.py:369-370), searches, applies the ignore filter of
+        mips.py:388-398 on the device and returns CUDA (scores [B, k], indices [B, k]); nothing
+        synchronises."""
+        import torch
+
+        from .index import filter_ignore
+
+        index = self._index()
+        q = queries
+        if not (isinstance(q, torch.Tensor) and q.is_cuda):
+            raise ValueError("search_device expects a CUDA tensor [B, d]")
+        if prepare and self.normalize and self.metric_type == METRIC_INNER_PRODUCT:
+            q = l2_normalize_(q.detach().float().contiguous().clone())
+        if ignore_indexes is None:
+            return index.search(q, k)
+        s, i = index.search(q, k + 1)
+        return filter_ignore(s, i, ignore_indexes, k)
+
     def np_search(self, x, k: int = 2) -> tuple:
         """mips.py:527-529: exhaustive cross-check over the stored embeddings."""
         index = self._index()

@@ -401,3 +401,93 @@ def test_tiny_splits_cold_start_stress():
             junk.random_(0, 255)                                   # 256 MiB of writes: evicts L2 / Infinity Cache
             s, i = ix.search(q, 5)
             assert np.array_equal(i, ei) and np.array_equal(s, es)
+
+
+def _big_properties(n, d, nq, k, plant_stride):
+    """Size-independent checks for indexes too large for the oracle: sortedness (ties by index), planted
+    duplicates retrieved as their own nearest neighbour, returned scores == canonical re-score of the
+    returned (query, document) pairs from independently regenerated rows, and agreement with the oracle
+    restricted to a window of the index that contains every planted document."""
+    ix = ram.MipsIndex(d)
+    ix.reserve(n)
+    ix.add_synthetic(n, row0=0, seed=synth.SEED_DOCS, kind=synth.KIND_GAUSS)
+    qd = ram.synth_fill(nq, d, 0, synth.SEED_QUERIES, synth.KIND_GAUSS, dtype="bf16")
+    plant_q = np.arange(0, nq, 16)
+    plant_doc = (plant_q.astype(np.int64) * plant_stride + 7) % n
+    rows = np.stack([synth.generate(synth.SEED_DOCS, int(r), 1, d, synth.KIND_GAUSS)[0] for r in plant_doc])
+    qd[torch.from_numpy(plant_q).cuda()] = torch.from_numpy(rows).cuda().bfloat16()
+    s, i = ix.search(qd, k)
+    torch.cuda.synchronize()
+    s, i = s.cpu().numpy(), i.cpu().numpy()
+    q = qd.float().cpu().numpy()
+    assert (i >= 0).all() and (i < n).all()
+    ds, di = np.diff(s, axis=1), np.diff(i, axis=1)
+    assert ((ds < 0) | ((ds == 0) & (di > 0))).all()
+    assert np.array_equal(i[plant_q, 0], plant_doc)
+    uniq = np.unique(i)
+    regen = {int(r): synth.generate(synth.SEED_DOCS, int(r), 1, d, synth.KIND_GAUSS)[0] for r in uniq}
+    docs = np.stack([regen[int(r)] for r in i.reshape(-1)]).reshape(nq, k, d)
+    canon = np.stack([orc.canonical_pairs(q[j:j + 1], docs[j], np.arange(k)[None, :])[0] for j in range(nq)])
+    assert np.array_equal(canon.astype(np.float32), s)
+    # no document outside the returned set beats the k-th result: check on a random sample of rows
+    rng = np.random.default_rng(1)
+    sample = rng.integers(0, n, 4096)
+    xs = np.concatenate([synth.generate(synth.SEED_DOCS, int(r), 1, d, synth.KIND_GAUSS) for r in sample])
+    sc = (q[:64].astype(np.float64) @ xs.astype(np.float64).T).astype(np.float32)
+    kth = s[:64, k - 1][:, None]
+    listed = (sample[None, :, None] == i[:64, None, :]).any(-1)
+    assert ((sc <= kth) | listed).all()
+    return ix.last_scan_ms()
+
+
+def test_cfg3_size_single_gpu_properties():
+    """BASELINE config 3's index (2^24 x 768 bf16, 25.8 GB) on ONE GPU, Q = 4096, k = 5."""
+    _big_properties(1 << 24, 768, 4096, 5, 4099)
+
+
+def test_cfg4_near_capacity_properties():
+    """BASELINE config 4's index (2^26 x 1024 bf16 = 137 GB, near one GPU's 288 GB HBM), Q = 4096, k = 5."""
+    _big_properties(1 << 26, 1024, 4096, 5, 16411)
+
+
+def test_device_resident_hook_matches_host_path(tmp_path):
+    """CUDA queries in, CUDA results out -- same answers as the NumPy call surface."""
+    n, d, k = 6000, 768, 5
+    emb = synth.generate(101, 0, n, d, synth.KIND_GAUSS) * 1.7
+    qs = synth.generate(102, 0, 9, d, synth.KIND_GAUSS)
+    for metric, normalize in ((0, True), (0, False), (1, True)):
+        m = ram.Mips(ram.MipsArgs(mips_metric_type=metric, mips_normalize=normalize, mips_tmp_folder=str(tmp_path)))
+        m.build_index(emb)
+        hs, hi = m.search(m._prepare_query(qs.copy()), k=k)
+        qd = torch.from_numpy(qs).cuda()
+        ds, di = m.search_device(qd, k=k)
+        assert ds.is_cuda and di.is_cuda and np.array_equal(di.cpu().numpy(), hi)
+        if not (normalize and metric == 0):      # device normalisation sums in another fp32 order
+            assert np.array_equal(ds.cpu().numpy(), hs)
+        ignore = [int(hi[j][j % k]) for j in range(9)]
+        fs, fi = m.search(m._prepare_query(qs.copy()), ignore_indexes=ignore, k=k)
+        gs, gi = m.search_device(qd, ignore_indexes=torch.tensor(ignore).cuda(), k=k)
+        assert gi.shape == (9, k) and np.array_equal(gi.cpu().numpy(), np.array(fi))
+        assert torch.equal(qd, torch.from_numpy(qs).cuda())        # caller's tensor untouched
+    # filter kernel vs the oracle's list semantics, incl. a missing id and padding
+    s = torch.tensor([[.9, .8, .7, .6], [.5, .4, .3, .2], [.1, float("-inf"), float("-inf"), float("-inf")]]).cuda()
+    i = torch.tensor([[4, 9, 2, 7], [1, 3, 5, 8], [6, -1, -1, -1]]).cuda()
+    os_, oi_ = ram.filter_ignore(s, i, [9, 77, 6], 3)
+    es, ei = orc.filter_ignore(s.cpu().numpy(), i.cpu().numpy(), [9, 77, 6], 3)
+    assert oi_.cpu().tolist() == [list(map(int, r)) for r in ei]
+    assert torch.equal(os_.cpu(), torch.tensor(np.array(es, dtype=np.float32)))
+
+
+def test_cosine_rescore_kernel():
+    torch.manual_seed(0)
+    q = torch.randn(7, 1, 768, device="cuda")
+    c = torch.randn(7, 5, 768, device="cuda")
+    ref = orc.cosine_rescore(q.cpu(), c.cpu())
+    out = ram.cosine_rescore(q, c)
+    assert out.shape == (7, 5) and torch.allclose(out.cpu(), ref, atol=2e-6, rtol=1e-5)
+    out16 = ram.cosine_rescore(q.bfloat16(), c.bfloat16())
+    ref16 = orc.cosine_rescore(q.bfloat16().float().cpu(), c.bfloat16().float().cpu())
+    assert torch.allclose(out16.cpu(), ref16, atol=2e-6, rtol=1e-5)
+    # memory_bias expansion of the hook (retriever_generator.py:188-192) stays a view op
+    bias = out.unsqueeze(-1).expand(-1, -1, 16).reshape(7, -1)
+    assert bias.shape == (7, 80) and torch.equal(bias[:, 16], out[:, 1])
