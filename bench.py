@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_FP8_TFLOPS = 5000.0    # dense fp8 MFMA (block-scaled K=64 instruction)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec
 
 
@@ -43,6 +44,8 @@ def parse():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--cpu-queries", type=int, default=768, help="queries in the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--index-dtype", default="bf16", choices=["bf16", "fp8_e4m3"],
+                    help="fp8_e4m3 = BASELINE config 5 (index and queries quantised to OCP e4m3, fp8 MFMA)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N > 1 path on ONE GPU (all ranks on cuda:0, host-staged collective)")
     return ap.parse_args()
@@ -63,8 +66,10 @@ def cpu_baseline(index, q_dev, args):
     except Exception:
         threads = os.cpu_count() or 1
     nq = min(args.cpu_queries, args.queries)
-    x = synth.bf16_bits_to_f32(index.rows_bf16())
+    x = synth.bf16_bits_to_f32(index.rows_raw()) if index.dtype == "bf16" else synth.e4m3_bits_to_f32(index.rows_raw())
     q = q_dev[:nq].float().cpu().numpy()
+    if index.dtype != "bf16":
+        q = synth.round_to_e4m3(q)  # the device quantises the queries the same way
     orc.inner_product(q[:2], x[:4096], k=args.k, normalize=False)  # warm-up
     t0 = time.perf_counter()
     s, i = orc.inner_product(q, x, k=args.k, normalize=False)
@@ -102,7 +107,9 @@ def main():
             dist.init_process_group("gloo")
 
     n, d, nq, k = args.rows, args.dim, args.queries, args.k
-    index = ram.ShardedMipsIndex(d, metric=ram.METRIC_IP, device=local_rank)
+    index = ram.ShardedMipsIndex(d, metric=ram.METRIC_IP, dtype=args.index_dtype, device=local_rank)
+    f8 = args.index_dtype != "bf16"
+    esz = 1 if f8 else 2
     t_build = time.perf_counter()
     index.add_synthetic_global(n, synth.SEED_DOCS, synth.KIND_GAUSS)
     q_dev = ram.synth_fill(nq, d, 0, synth.SEED_QUERIES, synth.KIND_GAUSS, dtype="bf16", device=local_rank)
@@ -146,7 +153,7 @@ def main():
     # algorithmic work of ONE scan launch on this rank: flops = 2 Q N_local d,
     # bytes = N_local d 2 (index, read once) + Q d 2 (queries) + Q k 12 (results)
     flops = 2.0 * nq * local_rows * d
-    bytes_ = local_rows * d * 2.0 + nq * d * 2.0 + nq * k * 12.0
+    bytes_ = local_rows * d * float(esz) + nq * d * float(esz) + nq * k * 12.0
     ach_tflops = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
     ach_gbs = bytes_ / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     # HBM-side traffic of one scan launch: PMC counters cannot be read from inside this process, so the
@@ -157,15 +164,16 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
             t = json.load(f)
-        if (t["rows_per_gpu"], t["dim"], t["queries"], t["k"]) == (local_rows, d, nq, k):
+        if (t["rows_per_gpu"], t["dim"], t["queries"], t["k"], t.get("dtype", "bf16")) == (local_rows, d, nq, k, args.index_dtype):
             traffic = (2.0 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0
             traffic_src = t["source"]
     except Exception:
         pass
     roofline = {
-        "bound": "mfma", "achieved": ach_tflops, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-        "frac": ach_tflops / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-        "kernel": "mips::scan_kernel_v3<8, 48, 1, 2, true, 0, true>", "kernel_ms": scan_ms,
+        "bound": "mfma", "achieved": ach_tflops, "peak": PEAK_FP8_TFLOPS if f8 else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+        "frac": ach_tflops / (PEAK_FP8_TFLOPS if f8 else PEAK_BF16_TFLOPS), "traffic": traffic, "traffic_source": traffic_src,
+        "kernel": "mips::scan_kernel_f8<8, 768, 2>" if f8 else "mips::scan_kernel_v3<8, 48, 1, 2, true, 0, true>",
+        "kernel_ms": scan_ms,
         "launches_timed": scan_launches,
         "flops_per_launch": flops, "bytes_per_launch": bytes_,
         "hbm_achieved": ach_gbs, "hbm_peak": PEAK_HBM_GBS, "hbm_unit": "GB/s", "hbm_frac": ach_gbs / PEAK_HBM_GBS,
@@ -185,12 +193,13 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "MIPS queries/sec (exact top-5, bf16 index)", "value": value, "unit": "queries/s",
+            "metric": f"MIPS queries/sec (exact top-{k}, {args.index_dtype} index)", "value": value, "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "fp8_e4m3" if f8 else "bf16",
             "data": "synthetic",
-            "config": {"workload": f"{n}x{d} bf16 index (counter-based Gaussian, seed 0xD0C5), Q={nq} bf16 queries "
-                                   f"resident in HBM, top-k={k}, exact; BASELINE config 2 at the defaults",
+            "config": {"workload": f"{n}x{d} {args.index_dtype} index (counter-based Gaussian, seed 0xD0C5), Q={nq} bf16 queries "
+                                   f"resident in HBM, top-k={k}, exact; BASELINE config 2 at the defaults "
+                                   f"(config 5 with --index-dtype fp8_e4m3)",
                        "index_rows": n, "dim": d, "queries": nq, "k": k,
                        "parallelism": f"row-sharded x{world} + 1 all-gather" if world > 1 else "single GPU",
                        "rows_per_gpu": local_rows},

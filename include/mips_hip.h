@@ -41,7 +41,7 @@ extern "C" {
 /* element types of caller buffers / of the index storage */
 #define MIPS_DTYPE_F32 0
 #define MIPS_DTYPE_BF16 1
-#define MIPS_DTYPE_FP8_E4M3 2 /* reserved: index storage dtype of BASELINE config 5 */
+#define MIPS_DTYPE_FP8_E4M3 2 /* OCP e4m3 bytes: index storage of BASELINE config 5 (d <= 1024, k <= 13) */
 
 /* faiss.METRIC_INNER_PRODUCT / faiss.METRIC_L2 as used by mips.py:306,316,369,371 */
 #define MIPS_METRIC_IP 0

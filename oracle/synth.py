@@ -103,3 +103,46 @@ def generate_blocked(seed: int, row0: int, nrows: int, d: int, kind: int, block:
         n = min(block, end - r)
         yield r, generate(seed, r, n, d, kind)
         r += n
+
+
+# --------------------------------------------------------------------------
+# OCP fp8 e4m3 ("e4m3fn": bias 7, 3 mantissa bits, max 448, 0x7f = NaN, no inf) -- the same integer
+# algorithm as csrc/aux_kernels.hpp::f32_to_e4m3 (round to nearest even, saturate, NaN stays NaN).
+# --------------------------------------------------------------------------
+def e4m3_bits(x: np.ndarray) -> np.ndarray:
+    """float32 -> uint8 e4m3 codes."""
+    f = np.ascontiguousarray(x, dtype=np.float32)
+    u = f.view(np.uint32)
+    sign = ((u >> np.uint32(24)) & np.uint32(0x80)).astype(np.uint8)
+    a = u & np.uint32(0x7FFFFFFF)
+    e = (a >> np.uint32(23)).astype(np.int64) - 127
+    m3 = ((a >> np.uint32(20)) & np.uint32(7)).astype(np.int64)
+    rem = (a & np.uint32(0xFFFFF)).astype(np.int64)
+    up = (rem > 0x80000) | ((rem == 0x80000) & ((m3 & 1) == 1))
+    m3 = m3 + up
+    ee = e + 7 + (m3 == 8)
+    m3 = np.where(m3 == 8, 0, m3)
+    normal = ((ee << 3) | m3).astype(np.int64)
+    with np.errstate(invalid="ignore", over="ignore"):
+        sub = np.rint(np.abs(f).astype(np.float32) * np.float32(512.0))
+    sub = np.where(np.isfinite(sub), sub, 0).astype(np.int64)
+    code = np.where(e < -6, sub, normal)
+    code = np.where(a >= np.uint32(0x43E00000), 0x7E, code)
+    code = np.where(a > np.uint32(0x7F800000), 0x7F, code)
+    return (sign | code.astype(np.uint8)).astype(np.uint8)
+
+
+def e4m3_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    b = np.asarray(b, dtype=np.uint8).astype(np.uint32)
+    e = (b >> np.uint32(3)) & np.uint32(15)
+    m = b & np.uint32(7)
+    sub = m.astype(np.float32) * np.float32(1.0 / 512.0)
+    norm = (((e + np.uint32(120)) << np.uint32(23)) | (m << np.uint32(20))).astype(np.uint32).view(np.float32)
+    v = np.where(e == 0, sub, norm).astype(np.float32)
+    v = np.where((e == 15) & (m == 7), np.float32(np.nan), v)
+    return np.where((b & np.uint32(0x80)) != 0, -v, v).astype(np.float32)
+
+
+def round_to_e4m3(x: np.ndarray) -> np.ndarray:
+    """float32 -> nearest e4m3 value (saturating), returned as float32."""
+    return e4m3_bits_to_f32(e4m3_bits(x))

@@ -15,6 +15,63 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
 
+// ---- OCP fp8 e4m3 ("e4m3fn": bias 7, 3 mantissa bits, max 448, 0x7f/0xff = NaN, no infinities).
+// Written with integer arithmetic so that oracle/synth.py::round_to_e4m3 is the same algorithm bit for
+// bit: round to nearest even, saturate to +-448, NaN stays NaN.
+__host__ __device__ __forceinline__ uint8_t f32_to_e4m3(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint8_t sign = (uint8_t)((u >> 24) & 0x80u);
+    const uint32_t a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint8_t)(sign | 0x7fu);  // NaN
+    if (a >= 0x43e00000u) return (uint8_t)(sign | 0x7eu); // |x| >= 448 (and inf): saturate
+    const int e = (int)(a >> 23) - 127;
+    if (e < -6) { // subnormal range of e4m3: multiples of 2^-9; 8 * 2^-9 is the smallest normal (code 0x08)
+        float ax;
+        memcpy(&ax, &a, 4);
+        const int qv = (int)rintf(ax * 512.0f); // round-to-nearest-even in the default rounding mode
+        return (uint8_t)(sign | (uint8_t)qv);
+    }
+    uint32_t m3 = (a >> 20) & 7u;
+    const uint32_t rem = a & 0xfffffu;
+    int ee = e + 7;
+    if (rem > 0x80000u || (rem == 0x80000u && (m3 & 1u))) {
+        if (++m3 == 8u) {
+            m3 = 0;
+            ++ee;
+        }
+    }
+    return (uint8_t)(sign | (uint8_t)((ee << 3) | (int)m3)); // < 0x7f: values that would round to 480+ were saturated above
+}
+__host__ __device__ __forceinline__ float e4m3_to_f32(uint32_t b) {
+    const uint32_t e = (b >> 3) & 15u, m = b & 7u;
+    float v;
+    if (e == 15u && m == 7u) {
+        const uint32_t nanbits = 0x7fc00000u;
+        memcpy(&v, &nanbits, 4);
+    } else if (e == 0u) {
+        v = (float)m * (1.0f / 512.0f);
+    } else {
+        const uint32_t bits = ((e + 120u) << 23) | (m << 20);
+        memcpy(&v, &bits, 4);
+    }
+    return (b & 0x80u) ? -v : v;
+}
+
+// element traits of the two index storage types: ELEMS per 16-byte chunk and the exact up-cast
+struct ElemBF16 {
+    typedef uint16_t type;
+    static constexpr int PER16 = 8;
+    __device__ static __forceinline__ float get(const u32x4& v, int e) {
+        return bf16_bits_to_f32((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+    }
+};
+struct ElemF8 {
+    typedef uint8_t type;
+    static constexpr int PER16 = 16;
+    __device__ static __forceinline__ float get(const u32x4& v, int e) { return e4m3_to_f32((v[e >> 2] >> ((e & 3) * 8)) & 0xffu); }
+};
+
 // ------------------------------------------------------------------ conversion into [rows][ld] bf16
 // one thread per 8 output elements; columns >= d are written as zero.
 template <typename SRC>
@@ -43,6 +100,31 @@ __global__ void convert_rows_kernel(const SRC* __restrict__ src, int64_t n, int 
         o[1] = v[2] | ((uint32_t)v[3] << 16);
         o[2] = v[4] | ((uint32_t)v[5] << 16);
         o[3] = v[6] | ((uint32_t)v[7] << 16);
+        *reinterpret_cast<u32x4*>(dst + row * ld + c0) = o;
+    }
+}
+
+// conversion into [rows][ld] e4m3 bytes; SRC = float, uint16_t (bf16 bits) or uint8_t (raw e4m3)
+template <typename SRC>
+__global__ void convert_rows_f8_kernel(const SRC* __restrict__ src, int64_t n, int d, uint8_t* dst, int ld) {
+    const int chunks = ld / 16;
+    const int64_t total = n * chunks;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / chunks;
+        const int c0 = (int)(t % chunks) * 16;
+        u32x4 o = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = c0 + e;
+            uint32_t b = 0;
+            if (c < d) {
+                if constexpr (sizeof(SRC) == 4) b = f32_to_e4m3(((const float*)src)[row * d + c]);
+                else if constexpr (sizeof(SRC) == 2) b = f32_to_e4m3(bf16_bits_to_f32(((const uint16_t*)src)[row * d + c]));
+                else b = ((const uint8_t*)src)[row * d + c];
+            }
+            o[e >> 2] |= b << ((e & 3) * 8);
+        }
         *reinterpret_cast<u32x4*>(dst + row * ld + c0) = o;
     }
 }
@@ -82,7 +164,7 @@ __device__ __forceinline__ float synth_value(uint64_t key, uint64_t col, int kin
     return (float)((int)(hsh % 255) - 127) / 64.0f;            // LATTICE
 }
 
-// out: bf16 [n][ld] (as_f32 == 0) or f32 [n][ld] (as_f32 == 1); columns >= d are zero
+// out: bf16 [n][ld] (as_f32 == 0), f32 [n][ld] (1) or e4m3 bytes [n][ld] (2); columns >= d are zero
 __global__ void synth_fill_kernel(void* out, int64_t n, int d, int ld, int64_t row0, uint64_t seed, int kind,
                                   int as_f32) {
     const int chunks = ld / 8;
@@ -95,7 +177,17 @@ __global__ void synth_fill_kernel(void* out, int64_t n, int d, int ld, int64_t r
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (c0 + e < d) ? synth_value(key, (uint64_t)(c0 + e), kind) : 0.f;
-        if (as_f32) {
+        if (as_f32 == 2) { // e4m3 bytes
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lo |= (uint32_t)f32_to_e4m3(v[e]) << (8 * e);
+                hi |= (uint32_t)f32_to_e4m3(v[4 + e]) << (8 * e);
+            }
+            uint32_t* o = reinterpret_cast<uint32_t*>((uint8_t*)out + row * ld + c0);
+            o[0] = lo;
+            o[1] = hi;
+        } else if (as_f32) {
             float* o = (float*)out + row * ld + c0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = v[e];
@@ -110,19 +202,18 @@ __global__ void synth_fill_kernel(void* out, int64_t n, int d, int ld, int64_t r
 }
 
 // ------------------------------------------------------------------ phi = max row |x|^2 (fp64, sequential)
-__global__ void row_sumsq_max_kernel(const uint16_t* rows, int64_t n, int ld, unsigned long long* out_bits) {
+template <typename EL>
+__global__ void row_sumsq_max_kernel(const typename EL::type* rows, int64_t n, int ld, unsigned long long* out_bits) {
     const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (r >= n) return;
-    const uint16_t* x = rows + r * ld;
+    const typename EL::type* x = rows + r * ld;
     double acc = 0.0;
-    for (int c = 0; c < ld; c += 8) {
+    for (int c = 0; c < ld; c += EL::PER16) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(x + c);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const double a = (double)bf16_bits_to_f32(v[e] & 0xffffu);
-            const double b = (double)bf16_bits_to_f32(v[e] >> 16);
+        for (int e = 0; e < EL::PER16; ++e) {
+            const double a = (double)EL::get(v, e);
             acc += a * a;
-            acc += b * b;
         }
     }
     // non-negative doubles order like their bit patterns
@@ -186,8 +277,8 @@ struct MergeArgs {
     const float* part_s; // [nq_pad][nsplit][2][KL]
     const int* part_i;
     int ncand;            // nsplit * 2 * KL
-    const uint16_t* docs; // [cap][ld]
-    const uint16_t* qbuf; // [nq_pad][ld]
+    const void* docs; // [cap][ld] index storage (bf16 bits or e4m3 bytes)
+    const void* qbuf; // [nq_pad][ld] staged queries, same element type
     int ld;
     int k;
     int metric;
@@ -206,7 +297,7 @@ struct MergeArgs {
 //     stored bf16 values (each product is exact in fp64, so the result does not depend on FMA
 //     contraction), cast to float -- the canonical score of include/mips_hip.h;
 //  4. rank the K candidates by (canonical score desc, idx asc) [L2: distance asc] and write the top k.
-template <int KL>
+template <int KL, typename EL>
 __global__ __launch_bounds__(64) void merge_rerank_kernel(MergeArgs p) {
     const int q = blockIdx.x;
     const int lane = threadIdx.x;
@@ -260,21 +351,17 @@ __global__ __launch_bounds__(64) void merge_rerank_kernel(MergeArgs p) {
     const bool valid = lane < KL && ci != IDX_NONE;
     double dot = 0.0, qq = 0.0;
     if (valid) {
-        const uint16_t* x = p.docs + (size_t)ci * p.ld;
-        const uint16_t* y = p.qbuf + (size_t)q * p.ld;
-        for (int c = 0; c < p.ld; c += 8) {
+        const typename EL::type* x = reinterpret_cast<const typename EL::type*>(p.docs) + (size_t)ci * p.ld;
+        const typename EL::type* y = reinterpret_cast<const typename EL::type*>(p.qbuf) + (size_t)q * p.ld;
+        for (int c = 0; c < p.ld; c += EL::PER16) {
             const u32x4 xv = *reinterpret_cast<const u32x4*>(x + c);
             const u32x4 yv = *reinterpret_cast<const u32x4*>(y + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const double x0 = (double)bf16_bits_to_f32(xv[e] & 0xffffu);
-                const double x1 = (double)bf16_bits_to_f32(xv[e] >> 16);
-                const double y0 = (double)bf16_bits_to_f32(yv[e] & 0xffffu);
-                const double y1 = (double)bf16_bits_to_f32(yv[e] >> 16);
-                dot += x0 * y0;
-                dot += x1 * y1;
-                qq += y0 * y0;
-                qq += y1 * y1;
+            for (int e = 0; e < EL::PER16; ++e) {
+                const double xe = (double)EL::get(xv, e);
+                const double ye = (double)EL::get(yv, e);
+                dot += xe * ye;
+                qq += ye * ye;
             }
         }
     }

@@ -14,6 +14,7 @@
 #include "aux_kernels.hpp"
 #include "scan_kernel.hpp"
 #include "scan_kernel_v3.hpp"
+#include "scan_kernel_f8.hpp"
 
 namespace {
 
@@ -88,12 +89,13 @@ int grid_for(int64_t items, int block) {
 struct mips_index {
     int device = 0;
     int64_t d = 0;
-    int ld = 0; // d padded to a multiple of BK
+    int ld = 0;    // row length in elements: d padded to a multiple of 64 (bf16) or 256 (fp8)
+    int esize = 2; // bytes per stored element
     int doc_dtype = MIPS_DTYPE_BF16;
     int metric = MIPS_METRIC_IP;
     int64_t ntotal = 0;
     int64_t capacity = 0; // rows allocated, multiple of TM
-    uint16_t* rows = nullptr;
+    uint8_t* rows = nullptr; // [capacity][ld] elements of esize bytes
     bool phi_valid = false;
     double phi = 0.0;
     Buffer qbuf, part_s, part_i, stage, out_s, out_i, scalar, gthr;
@@ -115,15 +117,15 @@ int grow(mips_index* ix, int64_t need_rows, hipStream_t st) {
     if (need_rows <= ix->capacity) return MIPS_OK;
     int64_t cap = std::max<int64_t>(need_rows, ix->capacity + ix->capacity / 2);
     cap = round_up(cap, kRowAlign);
-    uint16_t* fresh = nullptr;
-    const size_t bytes = (size_t)cap * ix->ld * sizeof(uint16_t);
+    uint8_t* fresh = nullptr;
+    const size_t row_bytes = (size_t)ix->ld * ix->esize;
+    const size_t bytes = (size_t)cap * row_bytes;
     hipError_t e = hipMalloc((void**)&fresh, bytes);
     if (e != hipSuccess) return fail(MIPS_E_NOMEM, "hipMalloc(%zu) for the index failed: %s", bytes, hipGetErrorString(e));
-    if (ix->ntotal > 0)
-        HIP_TRY(hipMemcpyAsync(fresh, ix->rows, (size_t)ix->ntotal * ix->ld * 2, hipMemcpyDeviceToDevice, st));
+    const size_t used = (size_t)ix->ntotal * row_bytes;
+    if (used) HIP_TRY(hipMemcpyAsync(fresh, ix->rows, used, hipMemcpyDeviceToDevice, st));
     // rows past ntotal are read by the last (ragged) tile: keep them defined
-    const size_t used = (size_t)ix->ntotal * ix->ld * 2;
-    HIP_TRY(hipMemsetAsync((char*)fresh + used, 0, bytes - used, st));
+    HIP_TRY(hipMemsetAsync(fresh + used, 0, bytes - used, st));
     if (ix->rows) {
         HIP_TRY(hipStreamSynchronize(st));
         (void)hipFree(ix->rows);
@@ -133,11 +135,11 @@ int grow(mips_index* ix, int64_t need_rows, hipStream_t st) {
     return MIPS_OK;
 }
 
-// convert [n][d] of src_dtype (host or device) into dst [n][ld] bf16 on the device
-int convert_into(mips_index* ix, const void* src, int64_t n, int src_dtype, int src_is_device, uint16_t* dst,
+// convert [n][d] of src_dtype (host or device) into dst [n][ld] of the index element type on the device
+int convert_into(mips_index* ix, const void* src, int64_t n, int src_dtype, int src_is_device, uint8_t* dst,
                  hipStream_t st) {
     const int d = (int)ix->d, ld = ix->ld;
-    const size_t esz = src_dtype == MIPS_DTYPE_F32 ? 4 : 2;
+    const size_t esz = src_dtype == MIPS_DTYPE_F32 ? 4 : src_dtype == MIPS_DTYPE_BF16 ? 2 : 1;
     const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(64u << 20) / (int64_t)(d * esz));
     for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
         const int64_t nr = std::min(chunk_rows, n - r0);
@@ -149,15 +151,30 @@ int convert_into(mips_index* ix, const void* src, int64_t n, int src_dtype, int 
             HIP_TRY(hipMemcpyAsync(ix->stage.p, s, (size_t)nr * d * esz, hipMemcpyHostToDevice, st));
             s = ix->stage.p;
         }
-        const int64_t items = nr * (ld / 8);
-        if (src_dtype == MIPS_DTYPE_F32)
-            mips::convert_rows_kernel<float><<<grid_for(items, 256), 256, 0, st>>>((const float*)s, nr, d, dst + r0 * ld, ld);
-        else
-            mips::convert_rows_kernel<uint16_t><<<grid_for(items, 256), 256, 0, st>>>((const uint16_t*)s, nr, d, dst + r0 * ld, ld);
+        uint8_t* out = dst + (size_t)r0 * ld * ix->esize;
+        if (ix->esize == 2) {
+            const int64_t items = nr * (ld / 8);
+            if (src_dtype == MIPS_DTYPE_F32)
+                mips::convert_rows_kernel<float><<<grid_for(items, 256), 256, 0, st>>>((const float*)s, nr, d, (uint16_t*)out, ld);
+            else
+                mips::convert_rows_kernel<uint16_t><<<grid_for(items, 256), 256, 0, st>>>((const uint16_t*)s, nr, d, (uint16_t*)out, ld);
+        } else {
+            const int64_t items = nr * (ld / 16);
+            if (src_dtype == MIPS_DTYPE_F32)
+                mips::convert_rows_f8_kernel<float><<<grid_for(items, 256), 256, 0, st>>>((const float*)s, nr, d, out, ld);
+            else if (src_dtype == MIPS_DTYPE_BF16)
+                mips::convert_rows_f8_kernel<uint16_t><<<grid_for(items, 256), 256, 0, st>>>((const uint16_t*)s, nr, d, out, ld);
+            else
+                mips::convert_rows_f8_kernel<uint8_t><<<grid_for(items, 256), 256, 0, st>>>((const uint8_t*)s, nr, d, out, ld);
+        }
         HIP_TRY(hipGetLastError());
         if (!src_is_device) HIP_TRY(hipStreamSynchronize(st));
     }
     return MIPS_OK;
+}
+
+bool src_dtype_ok(const mips_index* ix, int t) {
+    return t == MIPS_DTYPE_F32 || t == MIPS_DTYPE_BF16 || (t == MIPS_DTYPE_FP8_E4M3 && ix->esize == 1);
 }
 
 int compute_phi(mips_index* ix, hipStream_t st) {
@@ -166,8 +183,13 @@ int compute_phi(mips_index* ix, hipStream_t st) {
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(ix->scalar.p, 0, 8, st));
     if (ix->ntotal > 0) {
-        mips::row_sumsq_max_kernel<<<(int)((ix->ntotal + 255) / 256), 256, 0, st>>>(ix->rows, ix->ntotal, ix->ld,
-                                                                                    (unsigned long long*)ix->scalar.p);
+        const int grid = (int)((ix->ntotal + 255) / 256);
+        if (ix->esize == 2)
+            mips::row_sumsq_max_kernel<mips::ElemBF16><<<grid, 256, 0, st>>>((const uint16_t*)ix->rows, ix->ntotal, ix->ld,
+                                                                              (unsigned long long*)ix->scalar.p);
+        else
+            mips::row_sumsq_max_kernel<mips::ElemF8><<<grid, 256, 0, st>>>(ix->rows, ix->ntotal, ix->ld,
+                                                                            (unsigned long long*)ix->scalar.p);
         HIP_TRY(hipGetLastError());
     }
     unsigned long long bits = 0;
@@ -186,8 +208,14 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     int variant = ix->opt_variant;
     if (variant != 1 && variant != 3) variant = 3;
     const bool v3_dim = ix->ld == 256 || ix->ld == 512 || ix->ld == 768 || ix->ld == 1024;
-    if (!v3_dim || KL != 8) variant = 1; // K' > 8 lists do not fit the register budget next to the fragments
-    const int v3_waves = ix->ld == 1024 ? 4 : 8;
+    const bool f8 = ix->esize == 1; // e4m3 index: scan_kernel_f8 only (row lengths 256..1024, K' <= 16)
+    if (f8) {
+        if (!v3_dim || KL > 16) return fail(MIPS_E_UNSUPPORTED, "fp8 index: d must pad to 256/512/768/1024 and k <= 13");
+        variant = 3;
+    } else if (!v3_dim || KL != 8) {
+        variant = 1; // K' > 8 lists do not fit the register budget next to the bf16 fragments
+    }
+    const int v3_waves = (!f8 && ix->ld == 1024) ? 4 : 8;
     const int tm = variant == 1 ? mips::TM : mips::V3_DB;             // documents per scheduling unit ("tile")
     const int tn = variant == 1 ? mips::TN : v3_waves * 32;           // queries per workgroup
     const int lists = 2;                                              // running lists per (query, split)
@@ -217,7 +245,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     if (rc) return rc;
 
     mips::ScanArgs a;
-    a.docs = ix->rows;
+    a.docs = (const uint16_t*)ix->rows;
     a.qbuf = (const uint16_t*)ix->qbuf.p;
     a.ntotal = ix->ntotal;
     a.ld = ix->ld;
@@ -241,7 +269,27 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
 
     const int grid = qt_per_group * qgroups * nsplit;
     const int slot = ix->ev_next;
-    if (variant == 1) {
+    if (f8) {
+        if constexpr (KL <= 16) {
+            mips::ScanArgsF8 fa;
+            fa.docs = ix->rows;
+            fa.qbuf = (const uint8_t*)ix->qbuf.p;
+            fa.c = a;
+            const int lds = 3 * mips::V3_DB * ix->ld + 8 * 256;
+            auto gof8 = [&](auto kern) -> int {
+                HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HIP_TRY(hipEventRecord(ix->ev0[slot], st));
+                kern<<<grid, 512, lds, st>>>(fa);
+                return MIPS_OK;
+            };
+            int rc2;
+            if (ix->ld == 1024) rc2 = gof8(mips::scan_kernel_f8<KL, 1024, 2>);
+            else if (ix->ld == 768) rc2 = gof8(mips::scan_kernel_f8<KL, 768, 2>);
+            else if (ix->ld == 512) rc2 = gof8(mips::scan_kernel_f8<KL, 512, 2>);
+            else rc2 = gof8(mips::scan_kernel_f8<KL, 256, 2>);
+            if (rc2) return rc2;
+        }
+    } else if (variant == 1) {
         HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel<KL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     mips::SCAN_LDS_BYTES));
         HIP_TRY(hipEventRecord(ix->ev0[slot], st));
@@ -288,7 +336,8 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     m.out_s = d_out_s;
     m.out_i = d_out_i;
     m.out_packed = d_out_packed;
-    mips::merge_rerank_kernel<KL><<<(int)nq, 64, 0, st>>>(m);
+    if (f8) mips::merge_rerank_kernel<KL, mips::ElemF8><<<(int)nq, 64, 0, st>>>(m);
+    else mips::merge_rerank_kernel<KL, mips::ElemBF16><<<(int)nq, 64, 0, st>>>(m);
     HIP_TRY(hipGetLastError());
     return MIPS_OK;
 }
@@ -307,10 +356,10 @@ int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, 
     if (d <= 0 || d > (1 << 20)) return fail(MIPS_E_INVALID, "mips_index_create: bad dimension %lld", (long long)d);
     if (metric != MIPS_METRIC_IP && metric != MIPS_METRIC_L2)
         return fail(MIPS_E_INVALID, "mips_index_create: metric must be 0 (inner product) or 1 (L2), got %d", metric);
-    if (doc_dtype == MIPS_DTYPE_FP8_E4M3)
-        return fail(MIPS_E_UNSUPPORTED, "mips_index_create: fp8 e4m3 index storage is not implemented in this build");
-    if (doc_dtype != MIPS_DTYPE_BF16)
-        return fail(MIPS_E_INVALID, "mips_index_create: index storage dtype must be MIPS_DTYPE_BF16, got %d", doc_dtype);
+    if (doc_dtype != MIPS_DTYPE_BF16 && doc_dtype != MIPS_DTYPE_FP8_E4M3)
+        return fail(MIPS_E_INVALID, "mips_index_create: index storage dtype must be BF16 or FP8_E4M3, got %d", doc_dtype);
+    if (doc_dtype == MIPS_DTYPE_FP8_E4M3 && d > 1024)
+        return fail(MIPS_E_UNSUPPORTED, "mips_index_create: fp8 e4m3 storage supports d <= 1024 in this build");
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     if (device < 0 || device >= count) return fail(MIPS_E_INVALID, "mips_index_create: no HIP device %d (have %d)", device, count);
@@ -320,7 +369,8 @@ int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, 
     if (!ix) return fail(MIPS_E_NOMEM, "out of host memory");
     ix->device = device;
     ix->d = d;
-    ix->ld = (int)round_up(d, mips::BK);
+    ix->esize = doc_dtype == MIPS_DTYPE_FP8_E4M3 ? 1 : 2;
+    ix->ld = (int)round_up(d, ix->esize == 1 ? 256 : mips::BK);
     ix->doc_dtype = doc_dtype;
     ix->metric = metric;
     for (int e = 0; e < mips_index::kEvRing; ++e)
@@ -359,13 +409,14 @@ int mips_index_reserve(mips_index_t* ix, int64_t n) {
     if (n <= ix->capacity) return MIPS_OK;
     // exact reservation (no geometric slack)
     int64_t cap = round_up(n, kRowAlign);
-    uint16_t* fresh = nullptr;
-    const size_t bytes = (size_t)cap * ix->ld * 2;
+    uint8_t* fresh = nullptr;
+    const size_t row_bytes = (size_t)ix->ld * ix->esize;
+    const size_t bytes = (size_t)cap * row_bytes;
     hipError_t e = hipMalloc((void**)&fresh, bytes);
     if (e != hipSuccess) return fail(MIPS_E_NOMEM, "hipMalloc(%zu) for the index failed: %s", bytes, hipGetErrorString(e));
-    const size_t used = (size_t)ix->ntotal * ix->ld * 2;
+    const size_t used = (size_t)ix->ntotal * row_bytes;
     if (used) HIP_TRY(hipMemcpy(fresh, ix->rows, used, hipMemcpyDeviceToDevice));
-    HIP_TRY(hipMemset((char*)fresh + used, 0, bytes - used));
+    HIP_TRY(hipMemset(fresh + used, 0, bytes - used));
     if (ix->rows) (void)hipFree(ix->rows);
     ix->rows = fresh;
     ix->capacity = cap;
@@ -375,15 +426,15 @@ int mips_index_reserve(mips_index_t* ix, int64_t n) {
 int mips_index_add(mips_index_t* ix, const void* rows, int64_t n, int src_dtype, int src_is_device, void* hip_stream) {
     if (!ix) return fail(MIPS_E_INVALID, "mips_index_add: index is NULL");
     if (n < 0 || (n > 0 && !rows)) return fail(MIPS_E_INVALID, "mips_index_add: bad rows / n");
-    if (src_dtype != MIPS_DTYPE_F32 && src_dtype != MIPS_DTYPE_BF16)
-        return fail(MIPS_E_INVALID, "mips_index_add: src_dtype must be F32 or BF16");
+    if (!src_dtype_ok(ix, src_dtype))
+        return fail(MIPS_E_INVALID, "mips_index_add: src_dtype must be F32 or BF16 (or FP8_E4M3 bytes for an fp8 index)");
     if (n == 0) return MIPS_OK;
     if (ix->ntotal + n > (int64_t)0x7fffff00) return fail(MIPS_E_UNSUPPORTED, "mips_index_add: more than 2^31 rows on one GPU");
     DeviceGuard g(ix->device);
     hipStream_t st = (hipStream_t)hip_stream;
     int rc = grow(ix, ix->ntotal + n, st);
     if (rc) return rc;
-    rc = convert_into(ix, rows, n, src_dtype, src_is_device, ix->rows + (size_t)ix->ntotal * ix->ld, st);
+    rc = convert_into(ix, rows, n, src_dtype, src_is_device, ix->rows + (size_t)ix->ntotal * ix->ld * ix->esize, st);
     if (rc) return rc;
     ix->ntotal += n;
     ix->phi_valid = false;
@@ -417,8 +468,9 @@ int mips_index_read_rows(mips_index_t* ix, int64_t row0, int64_t n, void* out_ho
     if (n == 0) return MIPS_OK;
     DeviceGuard g(ix->device);
     hipStream_t st = (hipStream_t)hip_stream;
-    HIP_TRY(hipMemcpy2DAsync(out_host_u16, (size_t)ix->d * 2, ix->rows + (size_t)row0 * ix->ld, (size_t)ix->ld * 2,
-                             (size_t)ix->d * 2, (size_t)n, hipMemcpyDeviceToHost, st));
+    const size_t es = (size_t)ix->esize;
+    HIP_TRY(hipMemcpy2DAsync(out_host_u16, (size_t)ix->d * es, ix->rows + (size_t)row0 * ix->ld * es, (size_t)ix->ld * es,
+                             (size_t)ix->d * es, (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return MIPS_OK;
 }
@@ -433,8 +485,8 @@ int mips_index_add_synthetic(mips_index_t* ix, int64_t n, int64_t row0, uint64_t
     int rc = grow(ix, ix->ntotal + n, st);
     if (rc) return rc;
     const int64_t items = n * (ix->ld / 8);
-    mips::synth_fill_kernel<<<grid_for(items, 256), 256, 0, st>>>(ix->rows + (size_t)ix->ntotal * ix->ld, n, (int)ix->d,
-                                                                  ix->ld, row0, seed, kind, 0);
+    mips::synth_fill_kernel<<<grid_for(items, 256), 256, 0, st>>>(ix->rows + (size_t)ix->ntotal * ix->ld * ix->esize, n,
+                                                                  (int)ix->d, ix->ld, row0, seed, kind, ix->esize == 1 ? 2 : 0);
     HIP_TRY(hipGetLastError());
     ix->ntotal += n;
     ix->phi_valid = false;
@@ -446,13 +498,14 @@ int mips_synth_fill(void* out_device, int64_t n, int64_t d, int64_t row0, uint64
     if (!out_device || n < 0 || d <= 0 || d % 8 != 0)
         return fail(MIPS_E_INVALID, "mips_synth_fill: bad argument (d must be a positive multiple of 8)");
     if (kind < 0 || kind > 2) return fail(MIPS_E_INVALID, "mips_synth_fill: unknown kind %d", kind);
-    if (dtype != MIPS_DTYPE_F32 && dtype != MIPS_DTYPE_BF16) return fail(MIPS_E_INVALID, "mips_synth_fill: dtype must be F32 or BF16");
+    if (dtype != MIPS_DTYPE_F32 && dtype != MIPS_DTYPE_BF16 && dtype != MIPS_DTYPE_FP8_E4M3)
+        return fail(MIPS_E_INVALID, "mips_synth_fill: dtype must be F32, BF16 or FP8_E4M3");
     if (n == 0) return MIPS_OK;
     DeviceGuard g(device);
     if (!g.ok) return fail(MIPS_E_HIP, "hipSetDevice(%d) failed", device);
     const int64_t items = n * (d / 8);
     mips::synth_fill_kernel<<<grid_for(items, 256), 256, 0, (hipStream_t)hip_stream>>>(out_device, n, (int)d, (int)d, row0, seed,
-                                                                                      kind, dtype == MIPS_DTYPE_F32 ? 1 : 0);
+                                                                                      kind, dtype == MIPS_DTYPE_F32 ? 1 : dtype == MIPS_DTYPE_FP8_E4M3 ? 2 : 0);
     HIP_TRY(hipGetLastError());
     return MIPS_OK;
 }
@@ -462,7 +515,7 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
     if (!ix) return fail(MIPS_E_INVALID, "mips_search: index is NULL");
     if (nq < 0 || k < 0) return fail(MIPS_E_INVALID, "mips_search: negative nq or k");
     if (k > MIPS_MAX_K) return fail(MIPS_E_UNSUPPORTED, "mips_search: k = %d exceeds MIPS_MAX_K = %d", k, MIPS_MAX_K);
-    if (q_dtype != MIPS_DTYPE_F32 && q_dtype != MIPS_DTYPE_BF16) return fail(MIPS_E_INVALID, "mips_search: q_dtype must be F32 or BF16");
+    if (!src_dtype_ok(ix, q_dtype)) return fail(MIPS_E_INVALID, "mips_search: q_dtype must be F32 or BF16 (or FP8_E4M3 bytes for an fp8 index)");
     if (nq == 0 || k == 0) return MIPS_OK;
     if (!q || !out_idx || (!out_scores && !(flags & MIPS_OUT_PACKED))) return fail(MIPS_E_INVALID, "mips_search: NULL buffer");
     if (nq > (1 << 24)) return fail(MIPS_E_UNSUPPORTED, "mips_search: more than 2^24 queries in one call");
@@ -493,16 +546,13 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
             if (rc) return rc;
         }
         const int64_t nq_pad = round_up(nq, kQueryAlign);
-        int rc = ix->qbuf.ensure((size_t)nq_pad * ix->ld * 2);
+        const size_t row_bytes = (size_t)ix->ld * ix->esize;
+        int rc = ix->qbuf.ensure((size_t)nq_pad * row_bytes);
         if (rc) return rc;
-        uint16_t* qb = (uint16_t*)ix->qbuf.p;
+        uint8_t* qb = (uint8_t*)ix->qbuf.p;
         rc = convert_into(ix, q, nq, q_dtype, (flags & MIPS_Q_DEVICE) ? 1 : 0, qb, st);
         if (rc) return rc;
-        if (nq_pad > nq) {
-            const int64_t items = (nq_pad - nq) * (ix->ld / 8);
-            mips::zero_rows_kernel<<<grid_for(items, 256), 256, 0, st>>>(qb + (size_t)nq * ix->ld, nq_pad - nq, ix->ld);
-            HIP_TRY(hipGetLastError());
-        }
+        if (nq_pad > nq) HIP_TRY(hipMemsetAsync(qb + (size_t)nq * row_bytes, 0, (size_t)(nq_pad - nq) * row_bytes, st));
         if (k <= 5)
             rc = launch_search<8>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st);
         else if (k <= 13)

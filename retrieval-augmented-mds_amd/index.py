@@ -31,12 +31,13 @@ def _stream_handle(device: int) -> int:
 
 class MipsIndex:
     def __init__(self, d: int, metric: int = _lib.METRIC_IP, dtype: str = "bf16", device: int | None = None):
-        if dtype != "bf16":
-            raise NotImplementedError(f"index dtype {dtype!r}: this build stores bf16 only")
+        if dtype not in ("bf16", "fp8_e4m3"):
+            raise NotImplementedError(f"index dtype {dtype!r}: this build stores 'bf16' or 'fp8_e4m3'")
         self._lib = _lib.load()
         self.device = _lib.require_gpu(device)
         self._h = ctypes.c_void_p()
-        _lib.check(self._lib.mips_index_create(ctypes.byref(self._h), self.device, int(d), _lib.DTYPE_BF16,
+        self._code = _lib.DTYPE_BF16 if dtype == "bf16" else _lib.DTYPE_FP8_E4M3
+        _lib.check(self._lib.mips_index_create(ctypes.byref(self._h), self.device, int(d), self._code,
                                                int(metric)), "mips_index_create")
         self._d = int(d)
         self._metric = int(metric)
@@ -83,6 +84,8 @@ class MipsIndex:
                 code = _lib.DTYPE_F32
             elif x.dtype == torch.bfloat16:
                 code = _lib.DTYPE_BF16
+            elif x.dtype == getattr(torch, "float8_e4m3fn", None) and self._code == _lib.DTYPE_FP8_E4M3:
+                code = _lib.DTYPE_FP8_E4M3  # raw e4m3 bytes
             else:
                 x = x.float()
                 code = _lib.DTYPE_F32
@@ -98,6 +101,9 @@ class MipsIndex:
         if a.dtype == np.uint16:  # raw bf16 bit patterns
             a = np.ascontiguousarray(a)
             return a.ctypes.data, _lib.DTYPE_BF16, 0, a.shape[0], a
+        if a.dtype == np.uint8 and self._code == _lib.DTYPE_FP8_E4M3:  # raw e4m3 codes
+            a = np.ascontiguousarray(a)
+            return a.ctypes.data, _lib.DTYPE_FP8_E4M3, 0, a.shape[0], a
         a = np.ascontiguousarray(a, dtype=np.float32)
         return a.ctypes.data, _lib.DTYPE_F32, 0, a.shape[0], a
 
@@ -127,8 +133,18 @@ class MipsIndex:
         _lib.check(self._lib.mips_index_phi(self._h, ctypes.byref(out), _stream_handle(self.device)), "mips_index_phi")
         return out.value
 
+    def rows_raw(self, row0: int = 0, n: int | None = None) -> np.ndarray:
+        """Stored rows as raw codes: np.uint16 bf16 bits or np.uint8 e4m3 codes, [n, d]."""
+        n = self.ntotal - row0 if n is None else n
+        out = np.empty((n, self._d), dtype=np.uint16 if self._code == _lib.DTYPE_BF16 else np.uint8)
+        _lib.check(self._lib.mips_index_read_rows(self._h, int(row0), int(n), out.ctypes.data,
+                                                  _stream_handle(self.device)), "mips_index_read_rows")
+        return out
+
     def rows_bf16(self, row0: int = 0, n: int | None = None) -> np.ndarray:
         """Stored rows as bf16 bit patterns, np.uint16 [n, d]."""
+        if self._code != _lib.DTYPE_BF16:
+            raise TypeError("rows_bf16 on an fp8 index: use rows_raw")
         n = self.ntotal - row0 if n is None else n
         out = np.empty((n, self._d), dtype=np.uint16)
         _lib.check(self._lib.mips_index_read_rows(self._h, int(row0), int(n), out.ctypes.data,
@@ -207,14 +223,14 @@ class MipsIndex:
     # ------------------------------------------------------------------ persistence
     # Own format (the on-disk format is free, the call surface is kept):
     #   <path>/meta.json   {"format":1,"d":..,"ntotal":..,"metric":..,"dtype":"bf16", ...}
-    #   <path>/rows.bf16   raw little-endian bf16 bit patterns [ntotal, d]
+    #   <path>/rows.bf16   raw little-endian bf16 bit patterns [ntotal, d]   (rows.e4m3: e4m3 bytes)
     def save(self, path: str, extra: dict | None = None, chunk_rows: int = 1 << 16) -> None:
         """Replaces Dataset.save_faiss_index (sotasum/mips.py:536)."""
         os.makedirs(path, exist_ok=True)
         n = self.ntotal
-        with open(os.path.join(path, "rows.bf16"), "wb") as f:
+        with open(os.path.join(path, "rows." + ("bf16" if self.dtype == "bf16" else "e4m3")), "wb") as f:
             for r0 in range(0, n, chunk_rows):
-                f.write(self.rows_bf16(r0, min(chunk_rows, n - r0)).tobytes())
+                f.write(self.rows_raw(r0, min(chunk_rows, n - r0)).tobytes())
         meta = {"format": _FORMAT_VERSION, "d": self._d, "ntotal": n, "metric": self._metric, "dtype": self.dtype}
         if extra:
             meta.update(extra)
@@ -234,7 +250,9 @@ class MipsIndex:
         n, d = meta["ntotal"], meta["d"]
         lo, hi = (0, n) if row_range is None else row_range
         if hi > lo:
-            mm = np.memmap(os.path.join(path, "rows.bf16"), dtype=np.uint16, mode="r", shape=(n, d))
+            bf = meta["dtype"] == "bf16"
+            mm = np.memmap(os.path.join(path, "rows.bf16" if bf else "rows.e4m3"), dtype=np.uint16 if bf else np.uint8,
+                           mode="r", shape=(n, d))
             ix.reserve(hi - lo)
             for r0 in range(lo, hi, chunk_rows):
                 ix.add(np.asarray(mm[r0:min(hi, r0 + chunk_rows)]))
@@ -244,16 +262,17 @@ class MipsIndex:
 
 
 def synth_fill(n: int, d: int, row0: int, seed: int, kind: int, dtype="bf16", device: int | None = None):
-    """Device tensor [n, d] of generator values (torch.bfloat16 or torch.float32)."""
+    """Device tensor [n, d] of generator values: torch.bfloat16 ("bf16"), torch.float32 ("f32") or
+    e4m3 codes as torch.uint8 ("fp8_e4m3")."""
     import torch
 
     lib = _lib.load()
     dev = _lib.require_gpu(device)
-    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    tdt = {"bf16": torch.bfloat16, "f32": torch.float32, "fp8_e4m3": torch.uint8}[dtype]
+    code = {"bf16": _lib.DTYPE_BF16, "f32": _lib.DTYPE_F32, "fp8_e4m3": _lib.DTYPE_FP8_E4M3}[dtype]
     out = torch.empty((n, d), dtype=tdt, device=f"cuda:{dev}")
-    _lib.check(lib.mips_synth_fill(out.data_ptr(), n, d, row0, seed, kind,
-                                   _lib.DTYPE_BF16 if dtype == "bf16" else _lib.DTYPE_F32, dev,
-                                   _stream_handle(dev)), "mips_synth_fill")
+    _lib.check(lib.mips_synth_fill(out.data_ptr(), n, d, row0, seed, kind, code, dev, _stream_handle(dev)),
+               "mips_synth_fill")
     return out
 
 

@@ -491,3 +491,72 @@ def test_cosine_rescore_kernel():
     # memory_bias expansion of the hook (retriever_generator.py:188-192) stays a view op
     bias = out.unsqueeze(-1).expand(-1, -1, 16).reshape(7, -1)
     assert bias.shape == (7, 80) and torch.equal(bias[:, 16], out[:, 1])
+
+
+# ------------------------------------------------------------------ fp8 e4m3 index (BASELINE config 5)
+def _f8_index(x, metric=0):
+    ix = ram.MipsIndex(x.shape[1], metric=metric, dtype="fp8_e4m3")
+    ix.add(x)
+    return ix
+
+
+def test_fp8_quantizer_device_matches_host():
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(3000).astype(np.float32) * s for s in (1e-3, 0.05, 1, 30, 300)])
+    edge = np.array([0, -0.0, 448, 449, 463.9, 464, 1e9, -1e9, 2 ** -9, 2 ** -10, 2 ** -10 * 1.0001, 0.0175,
+                     np.inf, -np.inf, 2 ** -6, 2 ** -6 * 0.99, 240, 232, 0.0625 * 1.0625], dtype=np.float32)
+    x = np.concatenate([x, edge, np.zeros(768 * 20 - len(x) - len(edge), np.float32)]).reshape(20, 768)
+    ix = _f8_index(x)
+    assert np.array_equal(ix.rows_raw(), synth.e4m3_bits(x))
+    ix2 = ram.MipsIndex(768, dtype="fp8_e4m3")
+    ix2.add(torch.from_numpy(x).cuda().bfloat16())                 # bf16 source: quantised from the bf16 value
+    assert np.array_equal(ix2.rows_raw(), synth.e4m3_bits(synth.round_to_bf16(x)))
+    ix3 = ram.MipsIndex(768, dtype="fp8_e4m3")
+    ix3.add(synth.e4m3_bits(x))                                    # raw codes pass through
+    assert np.array_equal(ix3.rows_raw(), synth.e4m3_bits(x))
+    for kind in (synth.KIND_LATTICE_FP8, synth.KIND_GAUSS):
+        dev = ram.synth_fill(70, 768, 123, 9, kind, dtype="fp8_e4m3").cpu().numpy()
+        assert np.array_equal(dev, synth.e4m3_bits(synth.generate(9, 123, 70, 768, kind)))
+
+
+@pytest.mark.parametrize("n,nq,d,k", [(5000, 40, 768, 5), (70001, 300, 768, 5), (4099, 129, 1024, 10), (3000, 7, 256, 1),
+                                       (9000, 70, 500, 13), (33, 2, 512, 5)])
+def test_fp8_index_parity(n, nq, d, k):
+    """Index and queries quantised to e4m3; the oracle consumes the same quantised values."""
+    for kind in (synth.KIND_LATTICE_FP8, synth.KIND_GAUSS):
+        x = synth.generate(111, 0, n, d, kind)
+        q = synth.generate(112, 0, nq, d, kind)
+        xq, qq = synth.round_to_e4m3(x), synth.round_to_e4m3(q)
+        if kind == synth.KIND_LATTICE_FP8:
+            assert np.array_equal(xq, x)                            # lattice values are e4m3-exact
+        ix = _f8_index(x)
+        assert np.array_equal(synth.e4m3_bits_to_f32(ix.rows_raw()), xq)
+        s, i = ix.search(q, k)
+        fn = orc.search_exact_bruteforce if kind == synth.KIND_LATTICE_FP8 and n <= 9000 else orc.search_exact
+        es, ei = fn(qq, xq, k)
+        if kind == synth.KIND_LATTICE_FP8 and n > 9000:
+            continue                                                # ties need the brute-force oracle: small n only
+        assert np.array_equal(i, ei), f"kind {kind}: {(i != ei).any(axis=1).sum()} rows differ"
+        assert np.array_equal(s, es)
+
+
+def test_fp8_index_l2_padding_limits_and_persistence(tmp_path):
+    x = synth.generate(121, 0, 2000, 768, synth.KIND_GAUSS)
+    q = synth.generate(122, 0, 5, 768, synth.KIND_GAUSS)
+    xq, qq = synth.round_to_e4m3(x), synth.round_to_e4m3(q)
+    ix = _f8_index(x, metric=ram.METRIC_L2)
+    s, i = ix.search(q, 4)
+    es, ei = orc.search_exact(qq, xq, 4, metric=orc.METRIC_L2)
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+    small = _f8_index(x[:3])
+    s, i = small.search(q, 5)
+    assert (i[:, 3:] == -1).all() and np.isneginf(s[:, 3:]).all()
+    with pytest.raises(RuntimeError, match="k <= 13"):
+        small.search(q, 14)
+    with pytest.raises(RuntimeError, match="d <= 1024"):
+        ram.MipsIndex(2000, dtype="fp8_e4m3")
+    ix.save(str(tmp_path / "f8"))
+    back = ram.MipsIndex.load(str(tmp_path / "f8"))
+    assert back.dtype == "fp8_e4m3" and np.array_equal(back.rows_raw(), ix.rows_raw())
+    s2, i2 = back.search(torch.from_numpy(q).cuda(), 4)
+    assert np.array_equal(i2.cpu().numpy(), ei)

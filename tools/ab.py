@@ -1,7 +1,7 @@
 """A/B harness (GPU box): times scan-kernel launch variants interleaved in ONE process.
-usage: python tools_ab.py "qgroups=1" "qgroups=4" "qgroups=4,nsplit=32" ... [--rows N --queries Q --rounds R]"""
+usage: python tools/ab.py "qgroups=1" "qgroups=4" "qgroups=4,nsplit=32" ... [--rows N --queries Q --rounds R]"""
 import argparse, json, sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import retrieval_augmented_mds_amd as ram
 from oracle import synth
