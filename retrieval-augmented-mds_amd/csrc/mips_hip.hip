@@ -104,6 +104,7 @@ struct mips_index {
     // tuning knobs (mips_index_set_param); 0 = automatic
     int opt_nsplit = 0;
     int opt_qgroups = 0;
+    size_t err_off = 0; // word offset of the scan kernel's error flag inside gthr (0 = none this call)
     int opt_sub = 0;
     int opt_variant = 0; // 1 = scan_kernel (128x128 tiles, register staged), 3 = scan_kernel_v3 (query-stationary, LDS-DMA)
     hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
@@ -260,11 +261,15 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     a.part_s = (float*)ix->part_s.p;
     a.part_i = (int*)ix->part_i.p;
     a.gthr = nullptr;
+    a.err = nullptr;
+    ix->err_off = 0;
     if (variant == 3) {
-        rc = ix->gthr.ensure((size_t)nq_pad * 2 * sizeof(unsigned)); // one slot per (query, lane half)
+        rc = ix->gthr.ensure(((size_t)nq_pad * 2 + 4) * sizeof(unsigned)); // one slot per (query, lane half) + error word
         if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(ix->gthr.p, 0, (size_t)nq_pad * 2 * sizeof(unsigned), st));
+        HIP_TRY(hipMemsetAsync(ix->gthr.p, 0, ((size_t)nq_pad * 2 + 4) * sizeof(unsigned), st));
         a.gthr = (unsigned*)ix->gthr.p;
+        a.err = a.gthr + (size_t)nq_pad * 2;
+        ix->err_off = (size_t)nq_pad * 2;
     }
 
     const int grid = qt_per_group * qgroups * nsplit;
@@ -275,7 +280,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             fa.docs = ix->rows;
             fa.qbuf = (const uint8_t*)ix->qbuf.p;
             fa.c = a;
-            const int lds = 3 * mips::V3_DB * ix->ld + 8 * 256;
+            const int lds = 3 * mips::V3_DB * ix->ld + 8 * 256 + 16;
             auto gof8 = [&](auto kern) -> int {
                 HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
                 HIP_TRY(hipEventRecord(ix->ev0[slot], st));
@@ -295,7 +300,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         HIP_TRY(hipEventRecord(ix->ev0[slot], st));
         mips::scan_kernel<KL><<<grid, mips::SCAN_THREADS, mips::SCAN_LDS_BYTES, st>>>(a);
     } else if constexpr (KL == 8) {
-        const int lds = (v3_waves == 4 ? 2 : 3) * mips::V3_DB * ix->ld * 2 + v3_waves * 256; // ring + threshold slots
+        const int lds = (v3_waves == 4 ? 2 : 3) * mips::V3_DB * ix->ld * 2 + v3_waves * 256 + 16; // ring + threshold slots + arrival counter
         const int sub = ix->opt_sub; // A/B selector for tools_ab.py (0 = shipped configuration)
         auto go = [&](auto kern, int threads) -> int {
             HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -307,6 +312,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         if (ix->ld == 1024) rc2 = go(mips::scan_kernel_v3<KL, 64, 1, 4, false, 0, true, 4, 2>, 256);
         else if (ix->ld == 512) rc2 = go(mips::scan_kernel_v3<KL, 32, 1, 2, true>, 512);
         else if (ix->ld == 256) rc2 = go(mips::scan_kernel_v3<KL, 16, 1, 2, true>, 512);
+        else if (sub == 3) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, true, 8, 3, false>, 512);  // hardware s_barrier per block
         else if (sub == 2) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, false>, 512);            // DMA issued in one burst
         else if (sub == 4) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, false>, 512);   // no shared thresholds
         else if (sub == 5) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 3, true>, 512);             // prefetch depth 3
@@ -564,7 +570,11 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
     if (!out_dev) {
         HIP_TRY(hipMemcpyAsync(out_scores, d_s, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(out_idx, d_i, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        unsigned err = 0;
+        const bool have_err = ix->ntotal > 0 && ix->gthr.p != nullptr && ix->err_off != 0;
+        if (have_err) HIP_TRY(hipMemcpyAsync(&err, (unsigned*)ix->gthr.p + ix->err_off, sizeof err, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (err) return fail(MIPS_E_HIP, "mips_search: scan kernel synchronisation timed out (results invalid)");
     }
     return MIPS_OK;
 }

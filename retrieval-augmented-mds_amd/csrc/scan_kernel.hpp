@@ -56,7 +56,8 @@ struct ScanArgs {
     int splits_per_group; // nsplit / (8 / QG)
     float* part_s;        // [nq_pad][nsplit][2][KL]
     int* part_i;
-    unsigned* gthr;       // [nq_pad] shared per-query thresholds (order-preserving keys, 0 = none), v3 only
+    unsigned* gthr;       // [2 nq_pad] shared per-query thresholds (order-preserving keys, 0 = none), v3 only
+    unsigned* err;        // one word, zeroed per launch: set when a bounded spin gave up (never expected)
 };
 
 // order-preserving map float -> uint32 (larger float <=> larger key); key 0 is below every float

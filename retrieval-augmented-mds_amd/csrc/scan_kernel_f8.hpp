@@ -116,6 +116,32 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_f8(ScanArgsF8 pa) {
     const int rd_row = l31 * 128;
     const int rd_swz = (l31 >> 1) & 7;
 
+    // split barrier on an LDS arrival counter (see scan_kernel_v3.hpp)
+    const unsigned cnt_lds = (unsigned)(size_t)(lds_void*)(smem + STAGES * STAGE_BYTES + WAVES * 256);
+    unsigned arrivals_needed = 0;
+    constexpr int PER_BLOCK = PPW + 1;
+    auto arrive = [&]() {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_BLOCK) : "memory");
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(cnt_lds), "v"(1u) : "memory");
+#endif
+    };
+    auto wait_all = [&]() {
+        arrivals_needed += WAVES;
+        for (int spin = 0;; ++spin) {
+            unsigned v = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(cnt_lds) : "memory");
+#endif
+            if (__builtin_amdgcn_readfirstlane(v) >= arrivals_needed) break;
+            if (spin > (1 << 22)) {
+                if (lane == 0) *p.err = 1u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+
     auto block = [&](int blk, int stage, const unsigned char* pbase, int pstage) {
         const unsigned char* sa = smem + stage * STAGE_BYTES + rd_row;
         auto lds_frag = [&](int s) {
@@ -140,6 +166,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_f8(ScanArgsF8 pa) {
             if ((s % (KS / PPW)) == (KS / PPW) / 2) issue_piece(pbase, pstage, s / (KS / PPW));
             __builtin_amdgcn_sched_barrier(0);
         }
+        arrive(); // chain done, share of the next block landed; the epilogue below runs un-synchronised
         const int base = blk * V3_DB + (int)((thr_addr >> 5) & 4u);
         if ((int64_t)(blk + 1) * V3_DB > p.ntotal) {
 #pragma unroll
@@ -180,10 +207,11 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_f8(ScanArgsF8 pa) {
     }
     const unsigned char* pbase = nb > AHEAD ? first + AHEAD * blk_bytes : last;
     int stage = 0, pstage = AHEAD;
-    constexpr int PER_BLOCK = PPW + 1;
+    if (tid == 0) *reinterpret_cast<unsigned*>(smem + STAGES * STAGE_BYTES + WAVES * 256) = 0u;
+    __syncthreads(); // the one real barrier: arrival counter initialised
+    if (nb > 0) arrive();
     for (int i = 0; i < nb; ++i) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_BLOCK) : "memory");
-        __builtin_amdgcn_s_barrier();
+        wait_all();
         block(b0 + i, stage, pbase, pstage);
         if (i + AHEAD + 1 < nb) pbase += blk_bytes;
         stage = stage == STAGES - 1 ? 0 : stage + 1;

@@ -67,7 +67,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
 template <int KL, int KS16, int NQB, int AD, bool DMA_SPREAD, int TIMING_MODE = 0, bool GLOBAL_THR = true,
-          int WAVES = 8 / NQB, int STAGES = 3>
+          int WAVES = 8 / NQB, int STAGES = 3, bool SPLIT_BAR = true>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs p) {
     constexpr int V3_TN = WAVES * NQB * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -189,6 +189,41 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
         __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rsrc, (lds_void*)(smem + THR_AREA + wave * 256), 4, thr_addr, 0, 0, 16);
     };
 
+    // ---- split barrier (SPLIT_BAR): gfx950's s_barrier is arrive-and-wait in one instruction, so one wave
+    // taking the divergent insert path at the end of a block holds up all eight at the next barrier.  Here a
+    // wave ARRIVES right after its MFMA chain (one ds_add on an LDS counter, after the counted vmcnt wait that
+    // proves its DMA share of the NEXT block has landed), then runs its epilogue, and only WAITS -- polls
+    // for all WAVES arrivals -- before its next chain.  All-arrived(m) means: every share of block m + 1 has
+    // landed (RAW) and every wave has finished reading block m, whose stage the DMA of block m + 3 reuses
+    // (WAR).  The spin is bounded; giving up sets p.err (results are then invalid, the kernel still ends).
+    // The counter traffic is inline asm: for a volatile / atomic LDS access hipcc first drains vmcnt(0) (it
+    // cannot prove the word does not alias an in-flight LDS-DMA destination), which would stall the ring.
+    unsigned* arrive_cnt = reinterpret_cast<unsigned*>(smem + STAGES * STAGE_BYTES + WAVES * 256);
+    const unsigned cnt_lds = (unsigned)(size_t)(lds_void*)arrive_cnt; // 32-bit LDS byte address
+    unsigned arrivals_needed = 0;
+    constexpr int PER_BLOCK_OPS = PPW + ((GLOBAL_THR && NQB == 1) ? 1 : 0);
+    auto arrive = [&]() {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_BLOCK_OPS) : "memory");
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(cnt_lds), "v"(1u) : "memory");
+#endif
+    };
+    auto wait_all = [&]() {
+        arrivals_needed += WAVES;
+        for (int spin = 0;; ++spin) {
+            unsigned v = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(cnt_lds) : "memory");
+#endif
+            if (__builtin_amdgcn_readfirstlane(v) >= arrivals_needed) break;
+            if (spin > (1 << 22)) {
+                if (lane == 0) *p.err = 1u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+
     // scores block `blk` (ring stage `stage`); when pblk >= 0 the DMA pieces of block pblk are issued
     // one at a time between the MFMAs (spread over the chain: the partner wave keeps the matrix pipe busy
     // during an issue, which right after the barrier it could not, both waves being there together)
@@ -219,6 +254,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
             if (DMA_SPREAD && (s % (KS16 / PPW)) == (KS16 / PPW) / 2) issue_piece(pbase, pstage, s / (KS16 / PPW));
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (SPLIT_BAR) arrive(); // chain done + this wave's share of the next block landed; the epilogue runs un-synchronised
         if (TIMING_MODE == 1) { // diagnostic builds only (results are wrong): 1 = no epilogue at all
 #pragma unroll
             for (int n = 0; n < NQB; ++n) keep_alive(acc[n]);
@@ -285,9 +321,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
     // VMEM operations a wave issues per block: its DMA pieces and the threshold refresh; at the top of
     // block i everything older than the (STAGES - 2) youngest blocks' worth must have landed
     constexpr int PER_BLOCK = PPW + ((GLOBAL_THR && NQB == 1) ? 1 : 0);
+    if (SPLIT_BAR) {
+        if (tid == 0) *arrive_cnt = 0u;
+        __syncthreads(); // the one real barrier: counter initialised (its vmcnt(0) also settles the prologue's loads)
+        if (nb > 0) arrive();         // prologue arrival: this wave's share of block 0 has landed
+    }
     for (int i = 0; i < nb; ++i) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_BLOCK) : "memory");
-        __builtin_amdgcn_s_barrier(); // all shares of block i landed; everyone is done with block i-1
+        if (SPLIT_BAR) {
+            wait_all();
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_BLOCK) : "memory");
+            __builtin_amdgcn_s_barrier(); // all shares of block i landed; everyone is done with block i-1
+        }
         if (!DMA_SPREAD) issue(pbase, pstage);
         block(b0 + i, stage, pbase, pstage);
         if (i + AHEAD + 1 < nb) pbase += blk_bytes; // stops at the last block
