@@ -213,10 +213,12 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     if (f8) {
         if (!v3_dim || KL > 16) return fail(MIPS_E_UNSUPPORTED, "fp8 index: d must pad to 256/512/768/1024 and k <= 13");
         variant = 3;
-    } else if (!v3_dim || KL != 8) {
-        variant = 1; // K' > 8 lists do not fit the register budget next to the bf16 fragments
+    } else if (!v3_dim || (KL != 8 && ix->ld == 1024)) {
+        variant = 1; // no query-stationary configuration: generic tiles
     }
-    const int v3_waves = (!f8 && ix->ld == 1024) ? 4 : 8;
+    // K' = 8 at d <= 768: 8 waves, two per SIMD (256 registers each).  Longer lists (k > 5) or d = 1024 do
+    // not fit next to the fragments there: 4 waves, one per SIMD, 512 registers, 128 queries per workgroup.
+    const int v3_waves = (!f8 && (ix->ld == 1024 || KL != 8)) ? 4 : 8;
     const int tm = variant == 1 ? mips::TM : mips::V3_DB;             // documents per scheduling unit ("tile")
     const int tn = variant == 1 ? mips::TN : v3_waves * 32;           // queries per workgroup
     const int lists = 2;                                              // running lists per (query, split)
@@ -299,7 +301,21 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
                                     mips::SCAN_LDS_BYTES));
         HIP_TRY(hipEventRecord(ix->ev0[slot], st));
         mips::scan_kernel<KL><<<grid, mips::SCAN_THREADS, mips::SCAN_LDS_BYTES, st>>>(a);
-    } else if constexpr (KL == 8) {
+    } else if constexpr (KL != 8) {
+        // 4-wave configuration, 3-stage ring (d <= 768: 3 x 48 KiB)
+        const int lds = 3 * mips::V3_DB * ix->ld * 2 + 4 * 256 + 16;
+        auto go4 = [&](auto kern) -> int {
+            HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            HIP_TRY(hipEventRecord(ix->ev0[slot], st));
+            kern<<<grid, 256, lds, st>>>(a);
+            return MIPS_OK;
+        };
+        int rc2;
+        if (ix->ld == 768) rc2 = go4(mips::scan_kernel_v3<KL, 48, 1, 4, true, 0, true, 4, 3>);
+        else if (ix->ld == 512) rc2 = go4(mips::scan_kernel_v3<KL, 32, 1, 4, true, 0, true, 4, 3>);
+        else rc2 = go4(mips::scan_kernel_v3<KL, 16, 1, 4, true, 0, true, 4, 3>);
+        if (rc2) return rc2;
+    } else {
         const int lds = (v3_waves == 4 ? 2 : 3) * mips::V3_DB * ix->ld * 2 + v3_waves * 256 + 16; // ring + threshold slots + arrival counter
         const int sub = ix->opt_sub; // A/B selector for tools_ab.py (0 = shipped configuration)
         auto go = [&](auto kern, int threads) -> int {
@@ -320,8 +336,6 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         else if (sub == 9) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 2>, 512);          // timing only: pre-test only
         else rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true>, 512);
         if (rc2) return rc2;
-    } else {
-        return fail(MIPS_E_UNSUPPORTED, "internal: scan variant 3 requires K' = 8");
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ix->ev1[slot], st));

@@ -30,5 +30,5 @@ for nq in a.queries:
     wall = (time.perf_counter() - t0) / a.iters
     ms, n = ix.scan_timing(); scan = ms / n * 1e-3
     fl = 2.0 * nq * a.rows * a.dim; by = a.rows * a.dim * esz + nq * a.dim * esz + nq * a.k * 12.0
-    print(json.dumps({"dtype": a.dtype, "rows": a.rows, "dim": a.dim, "Q": nq, "scan_ms": scan * 1e3, "call_ms": wall * 1e3, "qps": nq / wall,
+    print(json.dumps({"dtype": a.dtype, "k": a.k, "rows": a.rows, "dim": a.dim, "Q": nq, "scan_ms": scan * 1e3, "call_ms": wall * 1e3, "qps": nq / wall,
                       "tflops": fl / scan / 1e12, "mfma_frac": fl / scan / (2.5e15 if esz == 2 else 5e15), "hbm_gbs": by / scan / 1e9, "hbm_frac": by / scan / 8e12}), flush=True)
