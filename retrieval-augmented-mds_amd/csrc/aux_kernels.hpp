@@ -297,7 +297,7 @@ struct MergeArgs {
 //     stored bf16 values (each product is exact in fp64, so the result does not depend on FMA
 //     contraction), cast to float -- the canonical score of include/mips_hip.h;
 //  4. rank the K candidates by (canonical score desc, idx asc) [L2: distance asc] and write the top k.
-template <int KL, typename EL>
+template <int KL, typename EL, bool L2>
 __global__ __launch_bounds__(64) void merge_rerank_kernel(MergeArgs p) {
     const int q = blockIdx.x;
     const int lane = threadIdx.x;
@@ -351,22 +351,40 @@ __global__ __launch_bounds__(64) void merge_rerank_kernel(MergeArgs p) {
     const bool valid = lane < KL && ci != IDX_NONE;
     double dot = 0.0, qq = 0.0;
     if (valid) {
+        // Same sequential fp64 sum as the oracle; only the LOADS run ahead (a ring of PF 16-byte chunks
+        // per operand), otherwise every iteration would expose one L2 round trip (96 of them at d = 768).
         const typename EL::type* x = reinterpret_cast<const typename EL::type*>(p.docs) + (size_t)ci * p.ld;
         const typename EL::type* y = reinterpret_cast<const typename EL::type*>(p.qbuf) + (size_t)q * p.ld;
-        for (int c = 0; c < p.ld; c += EL::PER16) {
-            const u32x4 xv = *reinterpret_cast<const u32x4*>(x + c);
-            const u32x4 yv = *reinterpret_cast<const u32x4*>(y + c);
+        constexpr int PF = 8;
+        const int nchunk = p.ld / EL::PER16;
+        u32x4 xr[PF], yr[PF];
 #pragma unroll
-            for (int e = 0; e < EL::PER16; ++e) {
-                const double xe = (double)EL::get(xv, e);
-                const double ye = (double)EL::get(yv, e);
-                dot += xe * ye;
-                qq += ye * ye;
+        for (int t = 0; t < PF; ++t) {
+            const int c = t < nchunk ? t : nchunk - 1;
+            xr[t] = *reinterpret_cast<const u32x4*>(x + c * EL::PER16);
+            yr[t] = *reinterpret_cast<const u32x4*>(y + c * EL::PER16);
+        }
+        for (int c0 = 0; c0 < nchunk; c0 += PF) {
+#pragma unroll
+            for (int t = 0; t < PF; ++t) {
+                const u32x4 xv = xr[t], yv = yr[t];
+                const int nx = c0 + PF + t < nchunk ? c0 + PF + t : nchunk - 1;
+                xr[t] = *reinterpret_cast<const u32x4*>(x + nx * EL::PER16);
+                yr[t] = *reinterpret_cast<const u32x4*>(y + nx * EL::PER16);
+                if (c0 + t < nchunk) {
+#pragma unroll
+                    for (int e = 0; e < EL::PER16; ++e) {
+                        const double xe = (double)EL::get(xv, e);
+                        const double ye = (double)EL::get(yv, e);
+                        dot += xe * ye;
+                        if (L2) qq += ye * ye; // |q|^2 is only needed for the L2 distances
+                    }
+                }
             }
         }
     }
     float outv, key;
-    if (p.metric == 1) { // L2 on phi-augmented vectors: |q|^2 + phi - 2 q.x, smaller is better
+    if (L2) { // L2 on phi-augmented vectors: |q|^2 + phi - 2 q.x, smaller is better
         outv = (float)(qq + p.phi - 2.0 * dot);
         key = -outv;
     } else {

@@ -356,8 +356,11 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     m.out_s = d_out_s;
     m.out_i = d_out_i;
     m.out_packed = d_out_packed;
-    if (f8) mips::merge_rerank_kernel<KL, mips::ElemF8><<<(int)nq, 64, 0, st>>>(m);
-    else mips::merge_rerank_kernel<KL, mips::ElemBF16><<<(int)nq, 64, 0, st>>>(m);
+    const bool l2 = ix->metric == MIPS_METRIC_L2;
+    if (f8 && l2) mips::merge_rerank_kernel<KL, mips::ElemF8, true><<<(int)nq, 64, 0, st>>>(m);
+    else if (f8) mips::merge_rerank_kernel<KL, mips::ElemF8, false><<<(int)nq, 64, 0, st>>>(m);
+    else if (l2) mips::merge_rerank_kernel<KL, mips::ElemBF16, true><<<(int)nq, 64, 0, st>>>(m);
+    else mips::merge_rerank_kernel<KL, mips::ElemBF16, false><<<(int)nq, 64, 0, st>>>(m);
     HIP_TRY(hipGetLastError());
     return MIPS_OK;
 }
