@@ -67,7 +67,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
 template <int KL, int KS16, int NQB, int AD, bool DMA_SPREAD, int TIMING_MODE = 0, bool GLOBAL_THR = true,
-          int WAVES = 8 / NQB, int STAGES = 3, bool SPLIT_BAR = true>
+          int WAVES = 8 / NQB, int STAGES = 3, bool SPLIT_BAR = true, bool NT_DOCS = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs p) {
     constexpr int V3_TN = WAVES * NQB * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
         const int slab = pc >> 2, rg = pc & 3;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(sbase + pc * 1024), 16,
                                                  (rg & 1) ? (lane_off0 ^ 64u) : lane_off0,
-                                                 rg * 8 * (int)row_bytes + slab * 128, 0, 0);
+                                                 rg * 8 * (int)row_bytes + slab * 128, 0, NT_DOCS ? 2 : 0);
     };
     auto issue = [&](const unsigned char* blk_base, int stage) {
 #pragma unroll
