@@ -330,6 +330,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         else if (ix->ld == 256) rc2 = go(mips::scan_kernel_v3<KL, 16, 1, 2, true>, 512);
         else if (sub == 3) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, true, 8, 3, false>, 512);  // hardware s_barrier per block
         else if (sub == 7) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, true, 8, 3, true, true>, 512);  // nt document DMA
+        else if (sub == 1) rc2 = go(mips::scan_kernel_v3<KL, 48, 2, 6, true, 0, false, 4, 3, true>, 256);  // 4 waves x 64 queries
         else if (sub == 2) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, false>, 512);            // DMA issued in one burst
         else if (sub == 4) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, false>, 512);   // no shared thresholds
         else if (sub == 5) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 3, true>, 512);             // prefetch depth 3

@@ -560,3 +560,19 @@ def test_fp8_index_l2_padding_limits_and_persistence(tmp_path):
     assert back.dtype == "fp8_e4m3" and np.array_equal(back.rows_raw(), ix.rows_raw())
     s2, i2 = back.search(torch.from_numpy(q).cuda(), 4)
     assert np.array_equal(i2.cpu().numpy(), ei)
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """The boundary is a C ABI: a plain-C program (no Python, no torch, host buffers) links libmips_hip.so,
+    builds an index, searches, and checks the result against integer arithmetic of its own."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(ram._lib.build())
+    exe = str(tmp_path / "c_abi_smoke")
+    subprocess.check_call(["gcc", "-O2", os.path.join(root, "tests", "c_abi_smoke.c"), "-I", os.path.join(root, "include"),
+                           "-L", libdir, "-lmips_hip", f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib",
+                           "-lm", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches: 0" in out.stdout
