@@ -576,3 +576,43 @@ def test_c_abi_from_plain_c(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "mismatches: 0" in out.stdout
+
+
+def test_nan_and_inf_documents_follow_flat_index_semantics():
+    """NaN scores never rank (FAISS heap comparisons are false for NaN; NumPy's argsort puts them last);
+    +inf scores rank first, ties by index; -inf scores rank last among real documents."""
+    x = synth.generate(131, 0, 600, 64, synth.KIND_LATTICE)
+    q = np.abs(synth.generate(132, 0, 4, 64, synth.KIND_LATTICE)) + 0.25      # strictly positive queries
+    x[5, 3] = np.nan
+    x[77, :] = np.nan
+    x[300, 0] = np.inf
+    x[100, 0] = np.inf
+    x[450, 1] = -np.inf
+    ix = _index(x)
+    s, i = ix.search(q, 5)
+    es, ei = orc.search_exact_bruteforce(q, x, 5)
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+    assert (i[:, 0] == 100).all() and (i[:, 1] == 300).all() and np.isposinf(s[:, :2]).all()
+    assert not np.isin(i, [5, 77, 450]).any()
+    s, i = ix.search(q, 29)
+    es, ei = orc.search_exact_bruteforce(q, x, 29)
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+
+
+def test_many_queries_and_non_default_stream():
+    n, nq, d, k = 20000, 9001, 768, 5
+    x = synth.generate(141, 0, n, d, synth.KIND_GAUSS)
+    q = synth.generate(142, 0, nq, d, synth.KIND_GAUSS)
+    es, ei = orc.search_exact(q, x, k)
+    ix = _index(x)
+    s, i = ix.search(q, k)
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+    side = torch.cuda.Stream()
+    qd = torch.from_numpy(q).cuda()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):                       # work is enqueued on the CURRENT torch stream
+        s2, i2 = ix.search(qd, k)
+        s3, i3 = ix.search(qd[:100], k)
+    side.synchronize()
+    assert np.array_equal(i2.cpu().numpy(), ei) and np.array_equal(s2.cpu().numpy(), es)
+    assert np.array_equal(i3.cpu().numpy(), ei[:100])
