@@ -54,15 +54,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libmips_hip.so (no CPU fallback exists)")
     os.makedirs(LIB_DIR, exist_ok=True)
-    tmp = LIB_PATH + f".tmp{os.getpid()}"
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-o", tmp, os.path.join(CSRC, "mips_hip.hip")]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    proc = subprocess.run(cmd, capture_output=True, text=True)
-    if proc.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
-    os.replace(tmp, LIB_PATH)
+    import fcntl
+
+    # one builder at a time (the ranks of a multi-GPU job import the package together)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():  # another process built it while we waited
+                return LIB_PATH
+            tmp = LIB_PATH + f".tmp{os.getpid()}"
+            cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+                   "-o", tmp, os.path.join(CSRC, "mips_hip.hip")]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            proc = subprocess.run(cmd, capture_output=True, text=True)
+            if proc.returncode != 0:
+                raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
+            os.replace(tmp, LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
