@@ -77,7 +77,11 @@ const char* mips_last_error(void);
 /* Create an empty index of dimension d on GPU `device`.
  * Replaces: datasets.Dataset.add_faiss_index(string_factory="Flat", metric_type=...) ->
  * faiss.IndexFlat(d, metric), sotasum/mips.py:333-340 and retriever_lightning.py:395-404.
- * doc_dtype is the storage type in HBM (MIPS_DTYPE_BF16). */
+ * doc_dtype is the storage type in HBM:
+ *   MIPS_DTYPE_BF16      2 B/element, inputs rounded to bf16 (RNE); the fast path
+ *   MIPS_DTYPE_FP8_E4M3  1 B/element, inputs AND queries rounded to OCP e4m3 (d <= 1024, k <= 13)
+ *   MIPS_DTYPE_F32       fp32-exact: results are those of an fp32 brute force on the caller's values
+ *                        (bf16 hi|lo planes for the scan + the fp32 rows for the exact re-score, 8 B/element). */
 int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, int metric);
 
 /* Free the index and its scratch.  Replaces Dataset.drop_index (mips.py:537). */
@@ -105,7 +109,7 @@ int mips_index_metric(const mips_index_t* index);
  * (mips.py:55-56, 316-324).  Synchronises the stream. */
 int mips_index_phi(mips_index_t* index, double* out_phi, void* hip_stream);
 
-/* Copy stored rows [row0, row0+n) as bf16 bit patterns (uint16, [n, d]) to HOST memory.
+/* Copy stored rows [row0, row0+n) in the index dtype ([n, d]: uint16 bf16 bits, uint8 e4m3 codes or float32) to HOST memory.
  * Used by save() (replaces Dataset.save_faiss_index, mips.py:536) and by tests. */
 int mips_index_read_rows(mips_index_t* index, int64_t row0, int64_t n, void* out_host_u16,
                          void* hip_stream);

@@ -66,6 +66,11 @@ struct ElemBF16 {
         return bf16_bits_to_f32((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
     }
 };
+struct ElemF32 {
+    typedef float type;
+    static constexpr int PER16 = 4;
+    __device__ static __forceinline__ float get(const u32x4& v, int e) { return __uint_as_float(v[e]); }
+};
 struct ElemF8 {
     typedef uint8_t type;
     static constexpr int PER16 = 16;
@@ -126,6 +131,43 @@ __global__ void convert_rows_f8_kernel(const SRC* __restrict__ src, int64_t n, i
             o[e >> 2] |= b << ((e & 3) * 8);
         }
         *reinterpret_cast<u32x4*>(dst + row * ld + c0) = o;
+    }
+}
+
+// fp32-exact mode: split fp32 (or bf16) rows [n][d] (pitch src_ld) into bf16 planes dst [n][2 * plane] =
+// [hi | lo], hi = bf16(x), lo = bf16(x - hi) (x - hi is exact in fp32), columns >= d zero; optionally keep
+// the fp32 originals in keep [n][plane] for the exact re-score.
+template <typename SRC>
+__global__ void split_rows_kernel(const SRC* __restrict__ src, int64_t n, int d, int src_ld, uint16_t* dst, int plane,
+                                  float* keep) {
+    const int chunks = plane / 8;
+    const int64_t total = n * chunks;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / chunks;
+        const int c0 = (int)(t % chunks) * 8;
+        uint16_t hi[8], lo[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            float x = 0.f;
+            if (c < d) {
+                if constexpr (sizeof(SRC) == 4) x = ((const float*)src)[row * src_ld + c];
+                else x = bf16_bits_to_f32(((const uint16_t*)src)[row * src_ld + c]);
+            }
+            hi[e] = f32_to_bf16_rne(x);
+            const float r = x - bf16_bits_to_f32(hi[e]);
+            lo[e] = (x == x && fabsf(x) != INFINITY) ? f32_to_bf16_rne(r) : (uint16_t)0; // inf - inf / NaN: keep lo = 0
+            if (keep) keep[row * plane + c] = x;
+        }
+        u32x4 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            oh[e] = hi[2 * e] | ((uint32_t)hi[2 * e + 1] << 16);
+            ol[e] = lo[2 * e] | ((uint32_t)lo[2 * e + 1] << 16);
+        }
+        *reinterpret_cast<u32x4*>(dst + row * 2 * plane + c0) = oh;
+        *reinterpret_cast<u32x4*>(dst + row * 2 * plane + plane + c0) = ol;
     }
 }
 

@@ -96,9 +96,13 @@ struct mips_index {
     int64_t ntotal = 0;
     int64_t capacity = 0; // rows allocated, multiple of TM
     uint8_t* rows = nullptr; // [capacity][ld] elements of esize bytes
+    // fp32-exact mode (doc_dtype F32): rows = bf16 planes [hi | lo] (ld = 2 * plane) for the scan,
+    // rows_f32 = the fp32 originals [capacity][plane] for the exact re-score; qf32 = staged fp32 queries
+    int plane = 0;
+    float* rows_f32 = nullptr;
     bool phi_valid = false;
     double phi = 0.0;
-    Buffer qbuf, part_s, part_i, stage, out_s, out_i, scalar, gthr;
+    Buffer qbuf, qf32, part_s, part_i, stage, out_s, out_i, scalar, gthr;
     // ring of HIP event pairs around the scan kernel (bench.py reads the average launch duration)
     static constexpr int kEvRing = 128;
     // tuning knobs (mips_index_set_param); 0 = automatic
@@ -127,18 +131,32 @@ int grow(mips_index* ix, int64_t need_rows, hipStream_t st) {
     if (used) HIP_TRY(hipMemcpyAsync(fresh, ix->rows, used, hipMemcpyDeviceToDevice, st));
     // rows past ntotal are read by the last (ragged) tile: keep them defined
     HIP_TRY(hipMemsetAsync(fresh + used, 0, bytes - used, st));
+    float* fresh32 = nullptr;
+    if (ix->plane > 0) {
+        const size_t b32 = (size_t)cap * ix->plane * sizeof(float);
+        e = hipMalloc((void**)&fresh32, b32);
+        if (e != hipSuccess) {
+            (void)hipFree(fresh);
+            return fail(MIPS_E_NOMEM, "hipMalloc(%zu) for the fp32 rows failed: %s", b32, hipGetErrorString(e));
+        }
+        const size_t u32 = (size_t)ix->ntotal * ix->plane * sizeof(float);
+        if (u32) HIP_TRY(hipMemcpyAsync(fresh32, ix->rows_f32, u32, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemsetAsync((char*)fresh32 + u32, 0, b32 - u32, st));
+    }
     if (ix->rows) {
         HIP_TRY(hipStreamSynchronize(st));
         (void)hipFree(ix->rows);
+        if (ix->rows_f32) (void)hipFree(ix->rows_f32);
     }
     ix->rows = fresh;
+    ix->rows_f32 = fresh32;
     ix->capacity = cap;
     return MIPS_OK;
 }
 
 // convert [n][d] of src_dtype (host or device) into dst [n][ld] of the index element type on the device
 int convert_into(mips_index* ix, const void* src, int64_t n, int src_dtype, int src_is_device, uint8_t* dst,
-                 hipStream_t st) {
+                 hipStream_t st, float* keep_f32 = nullptr) {
     const int d = (int)ix->d, ld = ix->ld;
     const size_t esz = src_dtype == MIPS_DTYPE_F32 ? 4 : src_dtype == MIPS_DTYPE_BF16 ? 2 : 1;
     const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(64u << 20) / (int64_t)(d * esz));
@@ -153,7 +171,14 @@ int convert_into(mips_index* ix, const void* src, int64_t n, int src_dtype, int 
             s = ix->stage.p;
         }
         uint8_t* out = dst + (size_t)r0 * ld * ix->esize;
-        if (ix->esize == 2) {
+        if (ix->plane > 0) { // fp32-exact mode: bf16 planes [hi | lo] + the fp32 originals
+            const int64_t items = nr * (ix->plane / 8);
+            float* keep = keep_f32 ? keep_f32 + (size_t)r0 * ix->plane : nullptr;
+            if (src_dtype == MIPS_DTYPE_F32)
+                mips::split_rows_kernel<float><<<grid_for(items, 256), 256, 0, st>>>((const float*)s, nr, d, d, (uint16_t*)out, ix->plane, keep);
+            else
+                mips::split_rows_kernel<uint16_t><<<grid_for(items, 256), 256, 0, st>>>((const uint16_t*)s, nr, d, d, (uint16_t*)out, ix->plane, keep);
+        } else if (ix->esize == 2) {
             const int64_t items = nr * (ld / 8);
             if (src_dtype == MIPS_DTYPE_F32)
                 mips::convert_rows_kernel<float><<<grid_for(items, 256), 256, 0, st>>>((const float*)s, nr, d, (uint16_t*)out, ld);
@@ -175,7 +200,7 @@ int convert_into(mips_index* ix, const void* src, int64_t n, int src_dtype, int 
 }
 
 bool src_dtype_ok(const mips_index* ix, int t) {
-    return t == MIPS_DTYPE_F32 || t == MIPS_DTYPE_BF16 || (t == MIPS_DTYPE_FP8_E4M3 && ix->esize == 1);
+    return t == MIPS_DTYPE_F32 || t == MIPS_DTYPE_BF16 || (t == MIPS_DTYPE_FP8_E4M3 && ix->esize == 1 && ix->plane == 0);
 }
 
 int compute_phi(mips_index* ix, hipStream_t st) {
@@ -185,7 +210,10 @@ int compute_phi(mips_index* ix, hipStream_t st) {
     HIP_TRY(hipMemsetAsync(ix->scalar.p, 0, 8, st));
     if (ix->ntotal > 0) {
         const int grid = (int)((ix->ntotal + 255) / 256);
-        if (ix->esize == 2)
+        if (ix->plane > 0)
+            mips::row_sumsq_max_kernel<mips::ElemF32><<<grid, 256, 0, st>>>(ix->rows_f32, ix->ntotal, ix->plane,
+                                                                             (unsigned long long*)ix->scalar.p);
+        else if (ix->esize == 2)
             mips::row_sumsq_max_kernel<mips::ElemBF16><<<grid, 256, 0, st>>>((const uint16_t*)ix->rows, ix->ntotal, ix->ld,
                                                                               (unsigned long long*)ix->scalar.p);
         else
@@ -210,10 +238,11 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     if (variant != 1 && variant != 3) variant = 3;
     const bool v3_dim = ix->ld == 256 || ix->ld == 512 || ix->ld == 768 || ix->ld == 1024;
     const bool f8 = ix->esize == 1; // e4m3 index: scan_kernel_f8 only (row lengths 256..1024, K' <= 16)
+    const bool f32x = ix->plane > 0; // fp32-exact mode: generic kernel over the [hi | lo] planes, three k segments
     if (f8) {
         if (!v3_dim || KL > 16) return fail(MIPS_E_UNSUPPORTED, "fp8 index: d must pad to 256/512/768/1024 and k <= 13");
         variant = 3;
-    } else if (!v3_dim || (KL != 8 && ix->ld == 1024)) {
+    } else if (f32x || !v3_dim || (KL != 8 && ix->ld == 1024)) {
         variant = 1; // no query-stationary configuration: generic tiles
     }
     // K' = 8 at d <= 768: 8 waves, two per SIMD (256 registers each).  Longer lists (k > 5) or d = 1024 do
@@ -252,7 +281,8 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     a.qbuf = (const uint16_t*)ix->qbuf.p;
     a.ntotal = ix->ntotal;
     a.ld = ix->ld;
-    a.ksteps = ix->ld / mips::BK;
+    a.ksteps = f32x ? 3 * ix->plane / mips::BK : ix->ld / mips::BK;
+    a.plane = ix->plane;
     a.ntiles = ntiles;
     a.tiles_per_split = tps;
     a.nsplit = nsplit;
@@ -350,9 +380,9 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     m.part_s = a.part_s;
     m.part_i = a.part_i;
     m.ncand = (int)ncand;
-    m.docs = ix->rows;
-    m.qbuf = a.qbuf;
-    m.ld = ix->ld;
+    m.docs = f32x ? (const void*)ix->rows_f32 : (const void*)ix->rows;
+    m.qbuf = f32x ? (const void*)ix->qf32.p : (const void*)a.qbuf;
+    m.ld = f32x ? ix->plane : ix->ld;
     m.k = k;
     m.metric = ix->metric;
     m.phi = ix->phi;
@@ -361,7 +391,9 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     m.out_i = d_out_i;
     m.out_packed = d_out_packed;
     const bool l2 = ix->metric == MIPS_METRIC_L2;
-    if (f8 && l2) mips::merge_rerank_kernel<KL, mips::ElemF8, true><<<(int)nq, 64, 0, st>>>(m);
+    if (f32x && l2) mips::merge_rerank_kernel<KL, mips::ElemF32, true><<<(int)nq, 64, 0, st>>>(m);
+    else if (f32x) mips::merge_rerank_kernel<KL, mips::ElemF32, false><<<(int)nq, 64, 0, st>>>(m);
+    else if (f8 && l2) mips::merge_rerank_kernel<KL, mips::ElemF8, true><<<(int)nq, 64, 0, st>>>(m);
     else if (f8) mips::merge_rerank_kernel<KL, mips::ElemF8, false><<<(int)nq, 64, 0, st>>>(m);
     else if (l2) mips::merge_rerank_kernel<KL, mips::ElemBF16, true><<<(int)nq, 64, 0, st>>>(m);
     else mips::merge_rerank_kernel<KL, mips::ElemBF16, false><<<(int)nq, 64, 0, st>>>(m);
@@ -383,8 +415,8 @@ int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, 
     if (d <= 0 || d > (1 << 20)) return fail(MIPS_E_INVALID, "mips_index_create: bad dimension %lld", (long long)d);
     if (metric != MIPS_METRIC_IP && metric != MIPS_METRIC_L2)
         return fail(MIPS_E_INVALID, "mips_index_create: metric must be 0 (inner product) or 1 (L2), got %d", metric);
-    if (doc_dtype != MIPS_DTYPE_BF16 && doc_dtype != MIPS_DTYPE_FP8_E4M3)
-        return fail(MIPS_E_INVALID, "mips_index_create: index storage dtype must be BF16 or FP8_E4M3, got %d", doc_dtype);
+    if (doc_dtype != MIPS_DTYPE_BF16 && doc_dtype != MIPS_DTYPE_FP8_E4M3 && doc_dtype != MIPS_DTYPE_F32)
+        return fail(MIPS_E_INVALID, "mips_index_create: index storage dtype must be BF16, FP8_E4M3 or F32, got %d", doc_dtype);
     if (doc_dtype == MIPS_DTYPE_FP8_E4M3 && d > 1024)
         return fail(MIPS_E_UNSUPPORTED, "mips_index_create: fp8 e4m3 storage supports d <= 1024 in this build");
     int count = 0;
@@ -398,6 +430,10 @@ int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, 
     ix->d = d;
     ix->esize = doc_dtype == MIPS_DTYPE_FP8_E4M3 ? 1 : 2;
     ix->ld = (int)round_up(d, ix->esize == 1 ? 256 : mips::BK);
+    if (doc_dtype == MIPS_DTYPE_F32) {
+        ix->plane = ix->ld;
+        ix->ld = 2 * ix->plane;
+    }
     ix->doc_dtype = doc_dtype;
     ix->metric = metric;
     for (int e = 0; e < mips_index::kEvRing; ++e)
@@ -422,6 +458,8 @@ int mips_index_destroy(mips_index_t* ix) {
     ix->out_i.release();
     ix->scalar.release();
     ix->gthr.release();
+    ix->qf32.release();
+    if (ix->rows_f32) (void)hipFree(ix->rows_f32);
     for (int e = 0; e < mips_index::kEvRing; ++e) {
         if (ix->ev0[e]) (void)hipEventDestroy(ix->ev0[e]);
         if (ix->ev1[e]) (void)hipEventDestroy(ix->ev1[e]);
@@ -444,6 +482,20 @@ int mips_index_reserve(mips_index_t* ix, int64_t n) {
     const size_t used = (size_t)ix->ntotal * row_bytes;
     if (used) HIP_TRY(hipMemcpy(fresh, ix->rows, used, hipMemcpyDeviceToDevice));
     HIP_TRY(hipMemset(fresh + used, 0, bytes - used));
+    if (ix->plane > 0) {
+        float* fresh32 = nullptr;
+        const size_t b32 = (size_t)cap * ix->plane * sizeof(float);
+        e = hipMalloc((void**)&fresh32, b32);
+        if (e != hipSuccess) {
+            (void)hipFree(fresh);
+            return fail(MIPS_E_NOMEM, "hipMalloc(%zu) for the fp32 rows failed: %s", b32, hipGetErrorString(e));
+        }
+        const size_t u32 = (size_t)ix->ntotal * ix->plane * sizeof(float);
+        if (u32) HIP_TRY(hipMemcpy(fresh32, ix->rows_f32, u32, hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemset((char*)fresh32 + u32, 0, b32 - u32));
+        if (ix->rows_f32) (void)hipFree(ix->rows_f32);
+        ix->rows_f32 = fresh32;
+    }
     if (ix->rows) (void)hipFree(ix->rows);
     ix->rows = fresh;
     ix->capacity = cap;
@@ -461,7 +513,8 @@ int mips_index_add(mips_index_t* ix, const void* rows, int64_t n, int src_dtype,
     hipStream_t st = (hipStream_t)hip_stream;
     int rc = grow(ix, ix->ntotal + n, st);
     if (rc) return rc;
-    rc = convert_into(ix, rows, n, src_dtype, src_is_device, ix->rows + (size_t)ix->ntotal * ix->ld * ix->esize, st);
+    rc = convert_into(ix, rows, n, src_dtype, src_is_device, ix->rows + (size_t)ix->ntotal * ix->ld * ix->esize, st,
+                      ix->plane > 0 ? ix->rows_f32 + (size_t)ix->ntotal * ix->plane : nullptr);
     if (rc) return rc;
     ix->ntotal += n;
     ix->phi_valid = false;
@@ -495,9 +548,14 @@ int mips_index_read_rows(mips_index_t* ix, int64_t row0, int64_t n, void* out_ho
     if (n == 0) return MIPS_OK;
     DeviceGuard g(ix->device);
     hipStream_t st = (hipStream_t)hip_stream;
-    const size_t es = (size_t)ix->esize;
-    HIP_TRY(hipMemcpy2DAsync(out_host_u16, (size_t)ix->d * es, ix->rows + (size_t)row0 * ix->ld * es, (size_t)ix->ld * es,
-                             (size_t)ix->d * es, (size_t)n, hipMemcpyDeviceToHost, st));
+    if (ix->plane > 0) { // fp32-exact mode: the fp32 originals
+        HIP_TRY(hipMemcpy2DAsync(out_host_u16, (size_t)ix->d * 4, ix->rows_f32 + (size_t)row0 * ix->plane, (size_t)ix->plane * 4,
+                                 (size_t)ix->d * 4, (size_t)n, hipMemcpyDeviceToHost, st));
+    } else {
+        const size_t es = (size_t)ix->esize;
+        HIP_TRY(hipMemcpy2DAsync(out_host_u16, (size_t)ix->d * es, ix->rows + (size_t)row0 * ix->ld * es, (size_t)ix->ld * es,
+                                 (size_t)ix->d * es, (size_t)n, hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipStreamSynchronize(st));
     return MIPS_OK;
 }
@@ -511,9 +569,17 @@ int mips_index_add_synthetic(mips_index_t* ix, int64_t n, int64_t row0, uint64_t
     hipStream_t st = (hipStream_t)hip_stream;
     int rc = grow(ix, ix->ntotal + n, st);
     if (rc) return rc;
-    const int64_t items = n * (ix->ld / 8);
-    mips::synth_fill_kernel<<<grid_for(items, 256), 256, 0, st>>>(ix->rows + (size_t)ix->ntotal * ix->ld * ix->esize, n,
-                                                                  (int)ix->d, ix->ld, row0, seed, kind, ix->esize == 1 ? 2 : 0);
+    if (ix->plane > 0) {
+        float* f32 = ix->rows_f32 + (size_t)ix->ntotal * ix->plane;
+        const int64_t items = n * (ix->plane / 8);
+        mips::synth_fill_kernel<<<grid_for(items, 256), 256, 0, st>>>(f32, n, (int)ix->d, ix->plane, row0, seed, kind, 1);
+        mips::split_rows_kernel<float><<<grid_for(items, 256), 256, 0, st>>>(
+            f32, n, (int)ix->d, ix->plane, (uint16_t*)(ix->rows + (size_t)ix->ntotal * ix->ld * 2), ix->plane, nullptr);
+    } else {
+        const int64_t items = n * (ix->ld / 8);
+        mips::synth_fill_kernel<<<grid_for(items, 256), 256, 0, st>>>(ix->rows + (size_t)ix->ntotal * ix->ld * ix->esize, n,
+                                                                      (int)ix->d, ix->ld, row0, seed, kind, ix->esize == 1 ? 2 : 0);
+    }
     HIP_TRY(hipGetLastError());
     ix->ntotal += n;
     ix->phi_valid = false;
@@ -577,7 +643,13 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
         int rc = ix->qbuf.ensure((size_t)nq_pad * row_bytes);
         if (rc) return rc;
         uint8_t* qb = (uint8_t*)ix->qbuf.p;
-        rc = convert_into(ix, q, nq, q_dtype, (flags & MIPS_Q_DEVICE) ? 1 : 0, qb, st);
+        float* qkeep = nullptr;
+        if (ix->plane > 0) {
+            rc = ix->qf32.ensure((size_t)nq_pad * ix->plane * sizeof(float));
+            if (rc) return rc;
+            qkeep = (float*)ix->qf32.p;
+        }
+        rc = convert_into(ix, q, nq, q_dtype, (flags & MIPS_Q_DEVICE) ? 1 : 0, qb, st, qkeep);
         if (rc) return rc;
         if (nq_pad > nq) HIP_TRY(hipMemsetAsync(qb + (size_t)nq * row_bytes, 0, (size_t)(nq_pad - nq) * row_bytes, st));
         if (k <= 5)

@@ -58,6 +58,9 @@ struct ScanArgs {
     int* part_i;
     unsigned* gthr;       // [2 nq_pad] shared per-query thresholds (order-preserving keys, 0 = none), v3 only
     unsigned* err;        // one word, zeroed per launch: set when a bounded spin gave up (never expected)
+    int plane;            // > 0: fp32-exact mode (generic kernel only).  Rows are two bf16 planes [hi | lo] of
+                          // `plane` elements each (x = hi + lo up to 2^-17 relative) and the k-loop runs three
+                          // segments hi.qhi + hi.qlo + lo.qhi; ld = 2 * plane, ksteps = 3 * plane / BK.
 };
 
 // order-preserving map float -> uint32 (larger float <=> larger key); key 0 is below every float
@@ -133,8 +136,16 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_kernel(ScanArgs p) {
 
     u32x4 ra[4], rb[4];
     auto gload = [&](int tile, int ks) {
-        const uint16_t* a = dbase + (int64_t)tile * TM * p.ld + ks * BK;
-        const uint16_t* b = qbase + ks * BK;
+        int kd = ks * BK, kq = ks * BK;
+        if (p.plane > 0) { // segment 0: hi.qhi, 1: hi.qlo, 2: lo.qhi
+            const int kpp = p.plane / BK;
+            const int seg = ks / kpp;
+            const int kk = (ks - seg * kpp) * BK;
+            kd = (seg == 2 ? p.plane : 0) + kk;
+            kq = (seg == 1 ? p.plane : 0) + kk;
+        }
+        const uint16_t* a = dbase + (int64_t)tile * TM * p.ld + kd;
+        const uint16_t* b = qbase + kq;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             ra[i] = *reinterpret_cast<const u32x4*>(a + i * row32);

@@ -31,12 +31,12 @@ def _stream_handle(device: int) -> int:
 
 class MipsIndex:
     def __init__(self, d: int, metric: int = _lib.METRIC_IP, dtype: str = "bf16", device: int | None = None):
-        if dtype not in ("bf16", "fp8_e4m3"):
-            raise NotImplementedError(f"index dtype {dtype!r}: this build stores 'bf16' or 'fp8_e4m3'")
+        if dtype not in ("bf16", "fp8_e4m3", "f32"):
+            raise NotImplementedError(f"index dtype {dtype!r}: this build stores 'bf16', 'fp8_e4m3' or 'f32'")
         self._lib = _lib.load()
         self.device = _lib.require_gpu(device)
         self._h = ctypes.c_void_p()
-        self._code = _lib.DTYPE_BF16 if dtype == "bf16" else _lib.DTYPE_FP8_E4M3
+        self._code = {"bf16": _lib.DTYPE_BF16, "fp8_e4m3": _lib.DTYPE_FP8_E4M3, "f32": _lib.DTYPE_F32}[dtype]
         _lib.check(self._lib.mips_index_create(ctypes.byref(self._h), self.device, int(d), self._code,
                                                int(metric)), "mips_index_create")
         self._d = int(d)
@@ -134,9 +134,10 @@ class MipsIndex:
         return out.value
 
     def rows_raw(self, row0: int = 0, n: int | None = None) -> np.ndarray:
-        """Stored rows as raw codes: np.uint16 bf16 bits or np.uint8 e4m3 codes, [n, d]."""
+        """Stored rows in the index dtype: np.uint16 bf16 bits, np.uint8 e4m3 codes or np.float32, [n, d]."""
         n = self.ntotal - row0 if n is None else n
-        out = np.empty((n, self._d), dtype=np.uint16 if self._code == _lib.DTYPE_BF16 else np.uint8)
+        npdt = {_lib.DTYPE_BF16: np.uint16, _lib.DTYPE_FP8_E4M3: np.uint8, _lib.DTYPE_F32: np.float32}[self._code]
+        out = np.empty((n, self._d), dtype=npdt)
         _lib.check(self._lib.mips_index_read_rows(self._h, int(row0), int(n), out.ctypes.data,
                                                   _stream_handle(self.device)), "mips_index_read_rows")
         return out
@@ -228,7 +229,7 @@ class MipsIndex:
         """Replaces Dataset.save_faiss_index (sotasum/mips.py:536)."""
         os.makedirs(path, exist_ok=True)
         n = self.ntotal
-        with open(os.path.join(path, "rows." + ("bf16" if self.dtype == "bf16" else "e4m3")), "wb") as f:
+        with open(os.path.join(path, "rows." + {"bf16": "bf16", "fp8_e4m3": "e4m3", "f32": "f32"}[self.dtype]), "wb") as f:
             for r0 in range(0, n, chunk_rows):
                 f.write(self.rows_raw(r0, min(chunk_rows, n - r0)).tobytes())
         meta = {"format": _FORMAT_VERSION, "d": self._d, "ntotal": n, "metric": self._metric, "dtype": self.dtype}
@@ -250,9 +251,8 @@ class MipsIndex:
         n, d = meta["ntotal"], meta["d"]
         lo, hi = (0, n) if row_range is None else row_range
         if hi > lo:
-            bf = meta["dtype"] == "bf16"
-            mm = np.memmap(os.path.join(path, "rows.bf16" if bf else "rows.e4m3"), dtype=np.uint16 if bf else np.uint8,
-                           mode="r", shape=(n, d))
+            ext, npdt = {"bf16": ("bf16", np.uint16), "fp8_e4m3": ("e4m3", np.uint8), "f32": ("f32", np.float32)}[meta["dtype"]]
+            mm = np.memmap(os.path.join(path, "rows." + ext), dtype=npdt, mode="r", shape=(n, d))
             ix.reserve(hi - lo)
             for r0 in range(lo, hi, chunk_rows):
                 ix.add(np.asarray(mm[r0:min(hi, r0 + chunk_rows)]))

@@ -59,7 +59,7 @@ class MipsArgs:
     copy_forcing: float = 0.0
     doc_sep: str = " <DOC_SEP> "
     # backend knobs (not in the reference)
-    mips_index_dtype: str = "bf16"
+    mips_index_dtype: str = "bf16"  # "bf16" (fast path) | "fp8_e4m3" | "f32" (fp32-exact: the reference's results on fp32 data)
     mips_device: int = None
 
 

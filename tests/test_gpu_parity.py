@@ -616,3 +616,69 @@ def test_many_queries_and_non_default_stream():
     side.synchronize()
     assert np.array_equal(i2.cpu().numpy(), ei) and np.array_equal(s2.cpu().numpy(), es)
     assert np.array_equal(i3.cpu().numpy(), ei[:100])
+
+
+# ------------------------------------------------------------------ fp32-exact index (the reference's own data type)
+def test_f32_exact_index_matches_reference_on_fp32_data(golden_dir):
+    """Golden G1b: the REAL reference `inner_product` on plain fp32 (not bf16-representable) inputs, raw
+    and normalised.  The fp32-exact index returns the reference's indices; scores agree to fp32 rounding
+    (ours are the exactly-rounded sums) and are bit-identical to the oracle's canonical definition."""
+    g = np.load(os.path.join(golden_dir, "g1b_inner_product_f32.npz"))
+    x, y, k = g["x"], g["y"], int(g["k"])
+    assert not np.array_equal(synth.round_to_bf16(y), y)            # really needs more than bf16
+    ix = ram.MipsIndex(y.shape[1], dtype="f32")
+    ix.add(y)
+    assert np.array_equal(ix.rows_raw(), y)
+    s, i = ix.search(x, k)
+    assert np.array_equal(i, g["indices_raw"])
+    np.testing.assert_allclose(s, g["scores_raw"], rtol=2e-6, atol=1e-6)
+    es, ei = orc.search_exact(x, y, k)
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+    # normalised variant (mips.py:554-556): same fp32 normalisation as the reference, then exact search
+    xn = x / np.linalg.norm(x, axis=1, keepdims=True)
+    yn = y / np.linalg.norm(y, axis=1, keepdims=True)
+    ixn = ram.MipsIndex(y.shape[1], dtype="f32")
+    ixn.add(yn)
+    s, i = ixn.search(xn, k)
+    assert np.array_equal(i, g["indices_norm"])
+    np.testing.assert_allclose(s, g["scores_norm"], rtol=2e-6, atol=1e-7)
+    # a bf16 index on the same data is allowed to differ -- that is what this mode is for
+    sb, ib = _index(y).search(x, k)
+    assert ib.shape == i.shape
+
+
+@pytest.mark.parametrize("n,nq,d,k,metric", [(10000, 8, 768, 5, 0), (30001, 130, 768, 10, 0), (5000, 33, 100, 5, 1),
+                                               (4000, 5, 1024, 29, 0)])
+def test_f32_exact_index_parity(tmp_path, n, nq, d, k, metric):
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal((n, d)) * rng.uniform(0.2, 3.0, (n, 1))).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    ix = ram.MipsIndex(d, metric=metric, dtype="f32")
+    ix.add(x[: n // 2])
+    ix.add(torch.from_numpy(x[n // 2:]).cuda())
+    s, i = ix.search(q, k)
+    es, ei = orc.search_exact(q, x, k, metric=metric)
+    assert np.array_equal(i, ei), f"{(i != ei).any(axis=1).sum()} rows differ"
+    assert np.array_equal(s, es)
+    sd, idd = ix.search(torch.from_numpy(q).cuda(), k)
+    assert np.array_equal(idd.cpu().numpy(), ei)
+    if n == 10000:
+        # the literal fp32 NumPy path of the reference (oracle port) picks the same neighbours
+        rs, ri = orc.inner_product(q, x, k, normalize=False)
+        assert np.array_equal(ri, i)
+        np.testing.assert_allclose(rs, s, rtol=1e-5, atol=1e-5)
+        ix.save(str(tmp_path / "f32"))
+        back = ram.MipsIndex.load(str(tmp_path / "f32"))
+        s2, i2 = back.search(q, k)
+        assert back.dtype == "f32" and np.array_equal(i2, ei) and np.array_equal(s2, es)
+
+
+def test_f32_exact_synthetic_and_ties():
+    ix = ram.MipsIndex(768, dtype="f32")
+    ix.add_synthetic(3000, row0=10, seed=5, kind=synth.KIND_LATTICE)
+    x = synth.generate(5, 10, 3000, 768, synth.KIND_LATTICE)
+    assert np.array_equal(ix.rows_raw(), x)
+    q = synth.generate(6, 0, 9, 768, synth.KIND_LATTICE)
+    s, i = ix.search(q, 5)
+    es, ei = orc.search_exact_bruteforce(q, x, 5)
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
