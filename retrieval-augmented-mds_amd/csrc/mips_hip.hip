@@ -236,13 +236,14 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // exists for a few row lengths only: 256 / 512 / 768 (8 waves, 2 per SIMD) and 1024 (4 waves, 1 per SIMD)
     int variant = ix->opt_variant;
     if (variant != 1 && variant != 3) variant = 3;
-    const bool v3_dim = ix->ld == 256 || ix->ld == 512 || ix->ld == 768 || ix->ld == 1024;
+    const bool v3_dim = (ix->ld % 128 == 0 && ix->ld <= 768) || ix->ld == 1024;
+    const bool v3_long = ix->ld == 256 || ix->ld == 512 || ix->ld == 768; // pitches with K' = 16 / 32 instances
     const bool f8 = ix->esize == 1; // e4m3 index: scan_kernel_f8 only (row lengths 256..1024, K' <= 16)
     const bool f32x = ix->plane > 0; // fp32-exact mode: generic kernel over the [hi | lo] planes, three k segments
     if (f8) {
-        if (!v3_dim || KL > 16) return fail(MIPS_E_UNSUPPORTED, "fp8 index: d must pad to 256/512/768/1024 and k <= 13");
+        if (ix->ld % 256 != 0 || ix->ld > 1024 || KL > 16) return fail(MIPS_E_UNSUPPORTED, "fp8 index: d must pad to 256/512/768/1024 and k <= 13");
         variant = 3;
-    } else if (f32x || !v3_dim || (KL != 8 && ix->ld == 1024)) {
+    } else if (f32x || !v3_dim || (KL != 8 && !v3_long)) {
         variant = 1; // no query-stationary configuration: generic tiles
     }
     // K' = 8 at d <= 768: 8 waves, two per SIMD (256 registers each).  Longer lists (k > 5) or d = 1024 do
@@ -255,8 +256,25 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     const int64_t nq_pad = round_up(nq, kQueryAlign);
     const int nqt = (int)((nq + tn - 1) / tn);
     const int ntiles = (int)((ix->ntotal + tm - 1) / tm);
-    int nsplit = ix->opt_nsplit > 0 ? (int)round_up(ix->opt_nsplit, 8)
-                                    : (int)round_up(std::max(1, (wg_target + nqt - 1) / nqt), 8);
+    // Index splits (a multiple of 8: one XCD group each).  The grid nqt x nsplit should come in whole
+    // "rounds" of wg_target resident workgroups: among the multiples of 8 up to 64 take the one whose last
+    // round is fullest (ties: fewer splits = longer streams, fewer lists to merge).
+    int nsplit;
+    if (ix->opt_nsplit > 0) {
+        nsplit = (int)round_up(ix->opt_nsplit, 8);
+    } else {
+        nsplit = (int)round_up(std::max(1, (wg_target + nqt - 1) / nqt), 8);
+        double best = -1.0;
+        for (int cand = 8; cand <= 64 && (int64_t)nqt * cand <= 16 * (int64_t)wg_target; cand += 8) {
+            const int64_t wgs = (int64_t)nqt * cand;
+            if (wgs < wg_target && cand < nsplit) continue; // never leave CUs idle on purpose
+            const double eff = (double)wgs / (double)(((wgs + wg_target - 1) / wg_target) * wg_target);
+            if (eff > best + 0.02) {
+                best = eff;
+                nsplit = cand;
+            }
+        }
+    }
     nsplit = (int)std::min<int64_t>(nsplit, round_up(ntiles, 8));
     const int tps = (ntiles + nsplit - 1) / nsplit;
     // query-tile groups per XCD.  Variant 1 re-reads its query tiles from L2 for every document tile:
@@ -356,8 +374,11 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         };
         int rc2;
         if (ix->ld == 1024) rc2 = go(mips::scan_kernel_v3<KL, 64, 1, 4, false, 0, true, 4, 2>, 256);
+        else if (ix->ld == 640) rc2 = go(mips::scan_kernel_v3<KL, 40, 1, 2, true>, 512);
         else if (ix->ld == 512) rc2 = go(mips::scan_kernel_v3<KL, 32, 1, 2, true>, 512);
+        else if (ix->ld == 384) rc2 = go(mips::scan_kernel_v3<KL, 24, 1, 2, true>, 512);
         else if (ix->ld == 256) rc2 = go(mips::scan_kernel_v3<KL, 16, 1, 2, true>, 512);
+        else if (ix->ld == 128) rc2 = go(mips::scan_kernel_v3<KL, 8, 1, 2, true>, 512);
         else if (sub == 3) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, true, 8, 3, false>, 512);  // hardware s_barrier per block
         else if (sub == 7) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, true, 8, 3, true, true>, 512);  // nt document DMA
         else if (sub == 1) rc2 = go(mips::scan_kernel_v3<KL, 48, 2, 6, true, 0, false, 4, 3, true>, 256);  // 4 waves x 64 queries
@@ -429,7 +450,12 @@ int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, 
     ix->device = device;
     ix->d = d;
     ix->esize = doc_dtype == MIPS_DTYPE_FP8_E4M3 ? 1 : 2;
-    ix->ld = (int)round_up(d, ix->esize == 1 ? 256 : mips::BK);
+    // Row pitch.  bf16: the query-stationary kernels exist for pitches of 128 .. 768 (multiples of 128) and
+    // 1024, so every d <= 1024 is padded to one of those (zero columns); beyond that the generic kernel
+    // takes multiples of 64.  fp8: multiples of 256 bytes.  fp32-exact: generic kernel over two planes.
+    if (doc_dtype == MIPS_DTYPE_FP8_E4M3) ix->ld = (int)round_up(d, 256);
+    else if (doc_dtype == MIPS_DTYPE_F32 || d > 1024) ix->ld = (int)round_up(d, mips::BK);
+    else ix->ld = d > 768 ? 1024 : (int)round_up(d, 128);
     if (doc_dtype == MIPS_DTYPE_F32) {
         ix->plane = ix->ld;
         ix->ld = 2 * ix->plane;
