@@ -172,7 +172,7 @@ def main():
     roofline = {
         "bound": "mfma", "achieved": ach_tflops, "peak": PEAK_FP8_TFLOPS if f8 else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": ach_tflops / (PEAK_FP8_TFLOPS if f8 else PEAK_BF16_TFLOPS), "traffic": traffic, "traffic_source": traffic_src,
-        "kernel": "mips::scan_kernel_f8<8, 768, 2>" if f8 else "mips::scan_kernel_v3<8, 48, 1, 2, true, 0, true>",
+        "kernel": "mips::scan_kernel_f8<8, 768, 2>" if f8 else "mips::scan_kernel_v3<8, 48, 1, 2, true, 0, true, 8, 3, true, false>",
         "kernel_ms": scan_ms,
         "launches_timed": scan_launches,
         "flops_per_launch": flops, "bytes_per_launch": bytes_,

@@ -331,16 +331,21 @@ struct MergeArgs {
     int64_t* out_packed; // optional [nq][k][2] = {float bits (zero-extended), global id}: the all-gather payload
 };
 
-// One wave per query.
+// Split merge + exact re-score, two launches:
+//
+// merge_select_kernel  -- one wave per query:
 //  1. every lane folds its strided share of the query's candidate lists into a private sorted K-list
 //     (full comparator: candidates do not arrive in index order here);
-//  2. KL rounds of wave-wide arg-best pop the K best candidates by MFMA score; lane r keeps the r-th;
-//  3. lanes 0..KL-1 re-score their candidate exactly: sequential fp64 sum over k of q[k]*x[k] on the
-//     stored bf16 values (each product is exact in fp64, so the result does not depend on FMA
-//     contraction), cast to float -- the canonical score of include/mips_hip.h;
-//  4. rank the K candidates by (canonical score desc, idx asc) [L2: distance asc] and write the top k.
-template <int KL, typename EL, bool L2>
-__global__ __launch_bounds__(64) void merge_rerank_kernel(MergeArgs p) {
+//  2. KL rounds of wave-wide arg-best pop the K best candidates by MFMA score; lane r keeps the r-th and
+//     writes its row id to cand[q][r].
+// rescore_rank_kernel  -- one THREAD per (query, candidate), 64 / KL queries per wave (every lane busy):
+//  3. exact re-score: sequential fp64 sum over k of q[k]*x[k] on the stored values (each product is exact
+//     in fp64, so the result does not depend on FMA contraction), cast to float -- the canonical score of
+//     include/mips_hip.h; only the loads run ahead (a ring of 16-byte chunks), the sum order is the oracle's;
+//  4. rank the KL candidates of a query inside their lane group by (canonical score desc, idx asc)
+//     [L2: distance asc] and write the top k (or the packed all-gather payload).
+template <int KL>
+__global__ __launch_bounds__(64) void merge_select_kernel(MergeArgs p, int* cand) {
     const int q = blockIdx.x;
     const int lane = threadIdx.x;
     const float* ps = p.part_s + (size_t)q * p.ncand;
@@ -358,8 +363,6 @@ __global__ __launch_bounds__(64) void merge_rerank_kernel(MergeArgs p) {
         const int id = pi[c];
         if (ranks_before(s, id, ls[KL - 1], li[KL - 1])) list_insert_full<KL>(ls, li, s, id);
     }
-
-    float cs = -INFINITY;
     int ci = IDX_NONE;
     for (int r = 0; r < KL; ++r) {
         const float hs = ls[0];
@@ -384,20 +387,25 @@ __global__ __launch_bounds__(64) void merge_rerank_kernel(MergeArgs p) {
             ls[KL - 1] = -INFINITY;
             li[KL - 1] = IDX_NONE;
         }
-        if (lane == r) {
-            cs = bs;
-            ci = bi;
-        }
+        if (lane == r) ci = bi;
     }
+    if (lane < KL) cand[(size_t)q * KL + lane] = ci;
+}
 
-    const bool valid = lane < KL && ci != IDX_NONE;
+template <int KL, typename EL, bool L2>
+__global__ __launch_bounds__(64) void rescore_rank_kernel(MergeArgs p, const int* cand, int64_t nq) {
+    constexpr int QPW = 64 / KL; // queries per wave
+    const int lane = threadIdx.x;
+    const int64_t q = (int64_t)blockIdx.x * QPW + lane / KL;
+    const int slot = lane % KL;
+    const bool inq = q < nq;
+    const int ci = inq ? cand[(size_t)q * KL + slot] : IDX_NONE;
+    const bool valid = ci != IDX_NONE;
     double dot = 0.0, qq = 0.0;
     if (valid) {
-        // Same sequential fp64 sum as the oracle; only the LOADS run ahead (a ring of PF 16-byte chunks
-        // per operand), otherwise every iteration would expose one L2 round trip (96 of them at d = 768).
         const typename EL::type* x = reinterpret_cast<const typename EL::type*>(p.docs) + (size_t)ci * p.ld;
         const typename EL::type* y = reinterpret_cast<const typename EL::type*>(p.qbuf) + (size_t)q * p.ld;
-        constexpr int PF = 8;
+        constexpr int PF = 4;
         const int nchunk = p.ld / EL::PER16;
         u32x4 xr[PF], yr[PF];
 #pragma unroll
@@ -434,16 +442,20 @@ __global__ __launch_bounds__(64) void merge_rerank_kernel(MergeArgs p) {
         key = outv;
     }
     if (!valid) key = -INFINITY;
-    (void)cs;
 
-    int rank = 0;
+    // rank inside the query's KL-lane group
+    const int gbase = lane - slot;
+    int rank = 0, nvalid = 0;
 #pragma unroll
     for (int jj = 0; jj < KL; ++jj) {
-        const float ok = __shfl(key, jj);
-        const int oi = __shfl(ci, jj);
-        if (oi != IDX_NONE && ranks_before(ok, oi, key, ci)) ++rank;
+        const float ok = __shfl(key, gbase + jj);
+        const int oi = __shfl(ci, gbase + jj);
+        if (oi != IDX_NONE) {
+            ++nvalid;
+            if (ranks_before(ok, oi, key, ci)) ++rank;
+        }
     }
-    const int nvalid = __popcll(__ballot(valid));
+    if (!inq) return;
     if (valid && rank < p.k) {
         const size_t o = (size_t)q * p.k + rank;
         if (p.out_packed) {
@@ -454,9 +466,9 @@ __global__ __launch_bounds__(64) void merge_rerank_kernel(MergeArgs p) {
             p.out_i[o] = (int64_t)ci + p.idx_offset;
         }
     }
-    if (lane < p.k && lane >= nvalid) {
-        const size_t o = (size_t)q * p.k + lane;
-        const float pad = p.metric == 1 ? INFINITY : -INFINITY;
+    if (slot < p.k && slot >= nvalid) {
+        const size_t o = (size_t)q * p.k + slot;
+        const float pad = L2 ? INFINITY : -INFINITY;
         if (p.out_packed) {
             p.out_packed[2 * o] = (int64_t)__float_as_uint(pad);
             p.out_packed[2 * o + 1] = -1;

@@ -102,7 +102,7 @@ struct mips_index {
     float* rows_f32 = nullptr;
     bool phi_valid = false;
     double phi = 0.0;
-    Buffer qbuf, qf32, part_s, part_i, stage, out_s, out_i, scalar, gthr;
+    Buffer qbuf, qf32, part_s, part_i, stage, out_s, out_i, scalar, gthr, cand;
     // ring of HIP event pairs around the scan kernel (bench.py reads the average launch duration)
     static constexpr int kEvRing = 128;
     // tuning knobs (mips_index_set_param); 0 = automatic
@@ -411,13 +411,20 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     m.out_s = d_out_s;
     m.out_i = d_out_i;
     m.out_packed = d_out_packed;
+    // (1) K' best candidates per query by MFMA score, (2) lane-packed exact re-score + final order
+    rc = ix->cand.ensure((size_t)nq * KL * sizeof(int));
+    if (rc) return rc;
+    int* cand = (int*)ix->cand.p;
+    mips::merge_select_kernel<KL><<<(int)nq, 64, 0, st>>>(m, cand);
+    HIP_TRY(hipGetLastError());
     const bool l2 = ix->metric == MIPS_METRIC_L2;
-    if (f32x && l2) mips::merge_rerank_kernel<KL, mips::ElemF32, true><<<(int)nq, 64, 0, st>>>(m);
-    else if (f32x) mips::merge_rerank_kernel<KL, mips::ElemF32, false><<<(int)nq, 64, 0, st>>>(m);
-    else if (f8 && l2) mips::merge_rerank_kernel<KL, mips::ElemF8, true><<<(int)nq, 64, 0, st>>>(m);
-    else if (f8) mips::merge_rerank_kernel<KL, mips::ElemF8, false><<<(int)nq, 64, 0, st>>>(m);
-    else if (l2) mips::merge_rerank_kernel<KL, mips::ElemBF16, true><<<(int)nq, 64, 0, st>>>(m);
-    else mips::merge_rerank_kernel<KL, mips::ElemBF16, false><<<(int)nq, 64, 0, st>>>(m);
+    const int rgrid = (int)((nq + (64 / KL) - 1) / (64 / KL));
+    if (f32x && l2) mips::rescore_rank_kernel<KL, mips::ElemF32, true><<<rgrid, 64, 0, st>>>(m, cand, nq);
+    else if (f32x) mips::rescore_rank_kernel<KL, mips::ElemF32, false><<<rgrid, 64, 0, st>>>(m, cand, nq);
+    else if (f8 && l2) mips::rescore_rank_kernel<KL, mips::ElemF8, true><<<rgrid, 64, 0, st>>>(m, cand, nq);
+    else if (f8) mips::rescore_rank_kernel<KL, mips::ElemF8, false><<<rgrid, 64, 0, st>>>(m, cand, nq);
+    else if (l2) mips::rescore_rank_kernel<KL, mips::ElemBF16, true><<<rgrid, 64, 0, st>>>(m, cand, nq);
+    else mips::rescore_rank_kernel<KL, mips::ElemBF16, false><<<rgrid, 64, 0, st>>>(m, cand, nq);
     HIP_TRY(hipGetLastError());
     return MIPS_OK;
 }
@@ -484,6 +491,7 @@ int mips_index_destroy(mips_index_t* ix) {
     ix->out_i.release();
     ix->scalar.release();
     ix->gthr.release();
+    ix->cand.release();
     ix->qf32.release();
     if (ix->rows_f32) (void)hipFree(ix->rows_f32);
     for (int e = 0; e < mips_index::kEvRing; ++e) {

@@ -12,7 +12,7 @@
 // documents scored against that one query.  A lane therefore owns one query's running list: the
 // threshold test is a per-lane register compare, no cross-lane traffic in the steady state.
 // Lanes l and l + 32 hold disjoint document rows of the same query; their two lists, and the lists
-// of the other index splits, are merged afterwards (merge_rerank_kernel).
+// of the other index splits, are merged afterwards (merge_select_kernel + rescore_rank_kernel).
 //
 // Within one list documents arrive in strictly increasing index order, so "insert only if strictly
 // greater than the current K-th" implements the tie rule "lowest index wins" without comparing
