@@ -109,6 +109,11 @@ int mips_index_metric(const mips_index_t* index);
  * (mips.py:55-56, 316-324).  Synchronises the stream. */
 int mips_index_phi(mips_index_t* index, double* out_phi, void* hip_stream);
 
+/* Override phi (>= 0).  A row-sharded index needs ONE phi for all shards -- the maximum of the shards'
+ * local values -- or L2 distances from different shards are not comparable.  Stays in force until
+ * mips_index_reset; the caller re-establishes it after adding rows. */
+int mips_index_set_phi(mips_index_t* index, double phi);
+
 /* Copy stored rows [row0, row0+n) in the index dtype ([n, d]: uint16 bf16 bits, uint8 e4m3 codes or float32) to HOST memory.
  * Used by save() (replaces Dataset.save_faiss_index, mips.py:536) and by tests. */
 int mips_index_read_rows(mips_index_t* index, int64_t row0, int64_t n, void* out_host_u16,

@@ -91,6 +91,7 @@ def _bind(lib):
         "mips_index_dim": (i64, [vp]),
         "mips_index_metric": (i32, [vp]),
         "mips_index_phi": (i32, [vp, c.POINTER(c.c_double), vp]),
+        "mips_index_set_phi": (i32, [vp, c.c_double]),
         "mips_index_read_rows": (i32, [vp, i64, i64, vp, vp]),
         "mips_index_add_synthetic": (i32, [vp, i64, i64, u64, i32, vp]),
         "mips_synth_fill": (i32, [vp, i64, i64, i64, u64, i32, i32, i32, vp]),
@@ -114,7 +115,7 @@ def _bind(lib):
 EXPORTS = (
     "mips_abi_version", "mips_last_error", "mips_index_create", "mips_index_destroy",
     "mips_index_reserve", "mips_index_add", "mips_index_reset", "mips_index_ntotal",
-    "mips_index_dim", "mips_index_metric", "mips_index_phi", "mips_index_read_rows",
+    "mips_index_dim", "mips_index_metric", "mips_index_phi", "mips_index_set_phi", "mips_index_read_rows",
     "mips_index_add_synthetic", "mips_synth_fill", "mips_search", "mips_merge_topk",
     "mips_merge_topk_packed", "mips_filter_ignore", "mips_cosine_rescore", "mips_l2_normalize", "mips_rows_max_sumsq", "mips_index_set_param", "mips_scan_timing",
 )

@@ -101,6 +101,7 @@ struct mips_index {
     int plane = 0;
     float* rows_f32 = nullptr;
     bool phi_valid = false;
+    bool phi_override = false; // phi was set from outside (global maximum of a sharded index): adds do not reset it
     double phi = 0.0;
     Buffer qbuf, qf32, part_s, part_i, stage, out_s, out_i, scalar, gthr, cand;
     // ring of HIP event pairs around the scan kernel (bench.py reads the average launch duration)
@@ -551,7 +552,7 @@ int mips_index_add(mips_index_t* ix, const void* rows, int64_t n, int src_dtype,
                       ix->plane > 0 ? ix->rows_f32 + (size_t)ix->ntotal * ix->plane : nullptr);
     if (rc) return rc;
     ix->ntotal += n;
-    ix->phi_valid = false;
+    if (!ix->phi_override) ix->phi_valid = false;
     return MIPS_OK;
 }
 
@@ -559,6 +560,7 @@ int mips_index_reset(mips_index_t* ix) {
     if (!ix) return fail(MIPS_E_INVALID, "mips_index_reset: index is NULL");
     ix->ntotal = 0;
     ix->phi_valid = false;
+    ix->phi_override = false;
     return MIPS_OK;
 }
 
@@ -572,6 +574,14 @@ int mips_index_phi(mips_index_t* ix, double* out_phi, void* hip_stream) {
     int rc = compute_phi(ix, (hipStream_t)hip_stream);
     if (rc) return rc;
     *out_phi = ix->phi;
+    return MIPS_OK;
+}
+
+int mips_index_set_phi(mips_index_t* ix, double phi) {
+    if (!ix || !(phi >= 0.0)) return fail(MIPS_E_INVALID, "mips_index_set_phi: bad argument");
+    ix->phi = phi;
+    ix->phi_valid = true;
+    ix->phi_override = true;
     return MIPS_OK;
 }
 

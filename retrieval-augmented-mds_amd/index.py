@@ -133,6 +133,10 @@ class MipsIndex:
         _lib.check(self._lib.mips_index_phi(self._h, ctypes.byref(out), _stream_handle(self.device)), "mips_index_phi")
         return out.value
 
+    def set_phi(self, phi: float) -> None:
+        """Override phi (row-sharded L2 indexes: the maximum over all shards)."""
+        _lib.check(self._lib.mips_index_set_phi(self._h, float(phi)), "mips_index_set_phi")
+
     def rows_raw(self, row0: int = 0, n: int | None = None) -> np.ndarray:
         """Stored rows in the index dtype: np.uint16 bf16 bits, np.uint8 e4m3 codes or np.float32, [n, d]."""
         n = self.ntotal - row0 if n is None else n

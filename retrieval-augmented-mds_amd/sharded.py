@@ -87,12 +87,28 @@ class ShardedMipsIndex:
         if self.local is not None and hi > lo:
             self.local.reserve(hi - lo)
             self.local.add(x[lo:hi])
+        self._sync_phi()
 
     def add_synthetic_global(self, n: int, seed: int, kind: int) -> None:
         lo, hi = self.set_global_size(n)
         if hi > lo:
             self.local.reserve(hi - lo)
             self.local.add_synthetic(hi - lo, row0=lo, seed=seed, kind=kind)
+        self._sync_phi()
+
+    def _sync_phi(self) -> None:
+        """L2 mode: phi = max_i |x_i|^2 must be the GLOBAL maximum (mips.py:316-324 computes it over the
+        whole knowledge base); one scalar all-reduce at build time, not on the search path."""
+        import torch
+        import torch.distributed as dist
+
+        if self.metric_type != _lib.METRIC_L2 or self.local is None or self.world == 1:
+            return
+        local = self.local.phi() if self.local.ntotal > 0 else 0.0
+        backend = dist.get_backend(self.group)
+        t = torch.tensor([local], dtype=torch.float64, device=f"cuda:{self.local.device}" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        self.local.set_phi(float(t.item()))
 
     @property
     def ntotal(self) -> int:

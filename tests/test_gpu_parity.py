@@ -332,6 +332,50 @@ def test_cfg2_full_size_properties_and_oracle_subset():
 
 
 # ------------------------------------------------------------------ N > 1 on one GPU (gloo rehearsal)
+def _rank_worker_l2(rank, world, port, n, nq, d, k, ret):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        rng = np.random.default_rng(3)
+        x = (synth.generate(151, 0, n, d, synth.KIND_GAUSS) * rng.uniform(0.3, 2.5, (n, 1))).astype(np.float32)
+        x = synth.round_to_bf16(x)                       # shards have very different max norms
+        q = synth.generate(152, 0, nq, d, synth.KIND_GAUSS)
+        ix = ram.ShardedMipsIndex(d, metric=ram.METRIC_L2, device=0)
+        ix.add_global(x)
+        s, i = ix.search(torch.from_numpy(q).cuda(), k)
+        es, ei = orc.search_exact(q, x, k, metric=orc.METRIC_L2)
+        ret[rank] = bool(np.array_equal(i.cpu().numpy(), ei) and np.array_equal(s.cpu().numpy(), es))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_l2_uses_global_phi():
+    import torch.multiprocessing as mp
+
+    port = 29700 + (os.getpid() % 2000)
+    ret = mp.Manager().dict()
+    mp.spawn(_rank_worker_l2, args=(3, port, 20001, 50, 768, 5, ret), nprocs=3, join=True)
+    assert dict(ret) == {r: True for r in range(3)}
+    # single-process form of the same thing: per-shard indexes need the common phi
+    n, d, k = 9000, 256, 4
+    rng = np.random.default_rng(4)
+    x = synth.round_to_bf16((synth.generate(153, 0, n, d, synth.KIND_GAUSS) * rng.uniform(0.3, 2.5, (n, 1))).astype(np.float32))
+    q = torch.from_numpy(synth.generate(154, 0, 20, d, synth.KIND_GAUSS)).cuda()
+    full = _index(x, metric=ram.METRIC_L2)
+    fs, fi = full.search(q, k)
+    parts = [_index(x[lo:hi], metric=ram.METRIC_L2) for lo, hi in (ram.shard_bounds(n, 2, r) for r in range(2))]
+    assert parts[0].phi() != parts[1].phi()
+    for p in parts:
+        p.set_phi(full.phi())
+    out = [p.search(q, k, ram.shard_bounds(n, 2, r)[0]) for r, p in enumerate(parts)]
+    ms, mi = ram.merge_topk(torch.cat([o[0] for o in out], 1), torch.cat([o[1] for o in out], 1), 2, k, metric=ram.METRIC_L2)
+    assert torch.equal(mi, fi) and torch.equal(ms, fs)
+
+
 def _rank_worker(rank, world, port, n, nq, d, k, ret):
     import torch.distributed as dist
 
