@@ -50,6 +50,7 @@ extern "C" {
 /* mips_search flags */
 #define MIPS_Q_DEVICE 1   /* queries pointer is device memory */
 #define MIPS_OUT_DEVICE 2 /* out_scores / out_idx are device memory */
+#define MIPS_FORCE_IP 8   /* rank by inner product for this call even on an L2 index (Mips.np_search, mips.py:527-529) */
 #define MIPS_OUT_PACKED 4 /* with MIPS_OUT_DEVICE: out_idx receives [nq, k, 2] int64 = {float32 score bits
                              (zero-extended), index}, the all-gather payload; out_scores is ignored */
 

@@ -101,6 +101,7 @@ struct mips_index {
     int plane = 0;
     float* rows_f32 = nullptr;
     bool phi_valid = false;
+    int call_metric = MIPS_METRIC_IP; // metric of the search in progress (index metric unless MIPS_FORCE_IP)
     bool phi_override = false; // phi was set from outside (global maximum of a sharded index): adds do not reset it
     double phi = 0.0;
     Buffer qbuf, qf32, part_s, part_i, stage, out_s, out_i, scalar, gthr, cand;
@@ -406,7 +407,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     m.qbuf = f32x ? (const void*)ix->qf32.p : (const void*)a.qbuf;
     m.ld = f32x ? ix->plane : ix->ld;
     m.k = k;
-    m.metric = ix->metric;
+    m.metric = ix->call_metric;
     m.phi = ix->phi;
     m.idx_offset = idx_offset;
     m.out_s = d_out_s;
@@ -418,7 +419,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     int* cand = (int*)ix->cand.p;
     mips::merge_select_kernel<KL><<<(int)nq, 64, 0, st>>>(m, cand);
     HIP_TRY(hipGetLastError());
-    const bool l2 = ix->metric == MIPS_METRIC_L2;
+    const bool l2 = ix->call_metric == MIPS_METRIC_L2;
     const int rgrid = (int)((nq + (64 / KL) - 1) / (64 / KL));
     if (f32x && l2) mips::rescore_rank_kernel<KL, mips::ElemF32, true><<<rgrid, 64, 0, st>>>(m, cand, nq);
     else if (f32x) mips::rescore_rank_kernel<KL, mips::ElemF32, false><<<rgrid, 64, 0, st>>>(m, cand, nq);
@@ -660,6 +661,7 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
     hipStream_t st = (hipStream_t)hip_stream;
     const bool out_dev = (flags & MIPS_OUT_DEVICE) != 0;
     const bool packed = (flags & MIPS_OUT_PACKED) != 0;
+    ix->call_metric = (flags & MIPS_FORCE_IP) ? MIPS_METRIC_IP : ix->metric;
     if (packed && !out_dev) return fail(MIPS_E_INVALID, "mips_search: MIPS_OUT_PACKED requires MIPS_OUT_DEVICE");
 
     float* d_s = out_scores;
@@ -675,10 +677,10 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
 
     if (ix->ntotal == 0) {
         const int64_t total = nq * k;
-        mips::fill_empty_kernel<<<(int)((total + 255) / 256), 256, 0, st>>>(d_s, d_i, packed ? d_i : nullptr, total, ix->metric);
+        mips::fill_empty_kernel<<<(int)((total + 255) / 256), 256, 0, st>>>(d_s, d_i, packed ? d_i : nullptr, total, ix->call_metric);
         HIP_TRY(hipGetLastError());
     } else {
-        if (ix->metric == MIPS_METRIC_L2) {
+        if (ix->call_metric == MIPS_METRIC_L2) {
             int rc = compute_phi(ix, st);
             if (rc) return rc;
         }

@@ -157,7 +157,7 @@ class MipsIndex:
         return out
 
     # ------------------------------------------------------------------ search
-    def search(self, x, k: int, idx_offset: int = 0):
+    def search(self, x, k: int, idx_offset: int = 0, force_ip: bool = False):
         """faiss Index.search(x, k) -> (D, I)  (sotasum/mips.py:383-386).
         NumPy in -> NumPy out; torch CUDA tensor in -> torch CUDA tensors out (stream-ordered, no
         synchronisation)."""
@@ -181,6 +181,8 @@ class MipsIndex:
             I = np.empty((nq, k), dtype=np.int64)
             flags = 0
             ds, di = D.ctypes.data, I.ctypes.data
+        if force_ip:
+            flags |= _lib.FORCE_IP  # inner-product ranking on an L2 index (Mips.np_search)
         with self._mutex:
             _lib.check(self._lib.mips_search(self._h, ptr, code, nq, k, ds, di, int(idx_offset), flags, stream),
                        "mips_search")

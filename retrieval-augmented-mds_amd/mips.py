@@ -328,7 +328,7 @@ class Mips:
         q = np.array(x, dtype=np.float32, copy=True)
         if self.normalize:
             q = self.l2_normalization(q)
-        return index.search(q, k)
+        return index.search(q, k, force_ip=True)  # the reference's cross-check is always an inner product
 
     # ------------------------------------------------------------------ forward (mips.py:402-463)
     def forward(self, queries: np.ndarray, aid: list = None, aid_counts=None, target_str: list = None,

@@ -726,3 +726,19 @@ def test_f32_exact_synthetic_and_ties():
     s, i = ix.search(q, 5)
     es, ei = orc.search_exact_bruteforce(q, x, 5)
     assert np.array_equal(i, ei) and np.array_equal(s, es)
+
+
+def test_np_search_is_inner_product_even_on_an_l2_index(tmp_path):
+    """Mips.np_search (mips.py:527-529) is the reference's exhaustive inner-product cross-check whatever the
+    index metric; on the L2 index it must not return distances."""
+    n, d, k = 4000, 768, 4
+    emb = synth.generate(161, 0, n, d, synth.KIND_GAUSS) * 1.3
+    qs = synth.generate(162, 0, 6, d, synth.KIND_GAUSS)
+    m = ram.Mips(ram.MipsArgs(mips_metric_type=1, mips_normalize=False, mips_tmp_folder=str(tmp_path)))
+    m.build_index(emb)
+    s, i = m.np_search(qs, k)
+    stored = synth.bf16_bits_to_f32(m.embeddings.get_index(m.index_name).faiss_index.rows_bf16())
+    es, ei = orc.search_exact(synth.round_to_bf16(qs), stored, k, metric=orc.METRIC_INNER_PRODUCT)
+    assert np.array_equal(i, ei) and np.array_equal(s, es) and (np.diff(s, axis=1) <= 0).all()
+    s2, i2 = m.search(m._prepare_query(qs.copy()), k=k)          # the index itself still answers in L2
+    assert (np.diff(s2, axis=1) >= 0).all() and np.array_equal(i2, ei)   # same neighbours (IP == augmented L2)
