@@ -15,6 +15,7 @@
 #include "scan_kernel.hpp"
 #include "scan_kernel_v3.hpp"
 #include "scan_kernel_f8.hpp"
+#include "scan_kernel_v4.hpp"
 
 namespace {
 
@@ -237,6 +238,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // variant 3 (query-stationary, LDS-DMA): the whole K of a wave's 32 queries lives in its VGPRs, so it
     // exists for a few row lengths only: 256 / 512 / 768 (8 waves, 2 per SIMD) and 1024 (4 waves, 1 per SIMD)
     int variant = ix->opt_variant;
+    const bool want_v4 = variant == 4 && ix->ld == 768 && KL == 8 && ix->esize == 2 && ix->plane == 0; // 16x16x32 experiment
     if (variant != 1 && variant != 3) variant = 3;
     const bool v3_dim = (ix->ld % 128 == 0 && ix->ld <= 768) || ix->ld == 1024;
     const bool v3_long = ix->ld == 256 || ix->ld == 512 || ix->ld == 768; // pitches with K' = 16 / 32 instances
@@ -253,7 +255,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     const int v3_waves = (!f8 && (ix->ld == 1024 || KL != 8)) ? 4 : 8;
     const int tm = variant == 1 ? mips::TM : mips::V3_DB;             // documents per scheduling unit ("tile")
     const int tn = variant == 1 ? mips::TN : v3_waves * 32;           // queries per workgroup
-    const int lists = 2;                                              // running lists per (query, split)
+    const int lists = want_v4 ? 4 : 2;                                // running lists per (query, split)
     const int wg_target = variant == 1 ? 512 : 256;                   // resident workgroups on 256 CUs
     const int64_t nq_pad = round_up(nq, kQueryAlign);
     const int nqt = (int)((nq + tn - 1) / tn);
@@ -290,7 +292,11 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     }
     const int qt_per_group = (nqt + qgroups - 1) / qgroups;
 
-    const size_t ncand = (size_t)nsplit * lists * KL;
+    // v4 keeps 4 sub-lists per (query, split); each needs k (<= 5) + 1 entries only, the re-score pool is
+    // still the K' = 8 best of their union
+    constexpr int V4_KLL = 6;
+    const bool short_lists = !want_v4 && KL == 8 && variant == 3 && !f8 && ix->ld == 768 && (ix->opt_sub == 10 || ix->opt_sub == 11);
+    const size_t ncand = (size_t)nsplit * lists * ((want_v4 || short_lists) ? V4_KLL : KL);
     int rc = ix->part_s.ensure((size_t)nq_pad * ncand * sizeof(float));
     if (rc) return rc;
     rc = ix->part_i.ensure((size_t)nq_pad * ncand * sizeof(int));
@@ -326,7 +332,14 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
 
     const int grid = qt_per_group * qgroups * nsplit;
     const int slot = ix->ev_next;
-    if (f8) {
+    if (want_v4) {
+        if constexpr (KL == 8) {
+            const int lds = 3 * mips::V3_DB * ix->ld * 2 + 8 * 256 + 16;
+            HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel_v4<V4_KLL, 24, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            HIP_TRY(hipEventRecord(ix->ev0[slot], st));
+            mips::scan_kernel_v4<V4_KLL, 24, 2><<<grid, 512, lds, st>>>(a);
+        }
+    } else if (f8) {
         if constexpr (KL <= 16) {
             mips::ScanArgsF8 fa;
             fa.docs = ix->rows;
@@ -384,6 +397,8 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         else if (sub == 3) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, true, 8, 3, false>, 512);  // hardware s_barrier per block
         else if (sub == 7) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, true, 8, 3, true, true>, 512);  // nt document DMA
         else if (sub == 1) rc2 = go(mips::scan_kernel_v3<KL, 48, 2, 6, true, 0, false, 4, 3, true>, 256);  // 4 waves x 64 queries
+        else if (sub == 10) rc2 = go(mips::scan_kernel_v3<6, 48, 1, 2, true>, 512);             // 6-entry lists
+        else if (sub == 11) rc2 = go(mips::scan_kernel_v3<6, 48, 1, 3, true>, 512);             // 6-entry lists, prefetch depth 3
         else if (sub == 2) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, false>, 512);            // DMA issued in one burst
         else if (sub == 4) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, false>, 512);   // no shared thresholds
         else if (sub == 5) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 3, true>, 512);             // prefetch depth 3

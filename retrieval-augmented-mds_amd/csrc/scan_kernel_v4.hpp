@@ -1,0 +1,256 @@
+// scan_kernel_v4: the query-stationary scan of scan_kernel_v3 on the 16x16x32 bf16 MFMA shape.
+//
+// Why: under this load the chip is power-limited (profiles/r1_final_split_barrier: MFMA pipe 81 % busy at
+// 1.55 GHz); the guide measures ~1.12-1.15x the FLOP/s of 32x32x16 for the 16x16x32 shape at equal cycles
+// because the chip holds a higher clock on it.
+//
+// Mapping (v_mfma_f32_16x16x32_bf16: lane l -> c = l & 15, g = l >> 4; A[row c][k = 8 g + j],
+// B[k = 8 g + j][col c], C/D col = c, row = 4 g + reg):
+//   * a wave still owns 32 stationary queries = two 16-query column blocks n = 0, 1 (192 fragment VGPRs);
+//   * a 32-document block is scored as two 16-document halves; per half and k32-step ONE A fragment feeds
+//     two MFMAs (one per query block), 4 accumulator registers each -> 8 accumulator VGPRs instead of 16,
+//     which pays for the second running list a lane now needs (lane (c, g) sees documents 4 g .. 4 g + 3 of
+//     each half for queries c and 16 + c);
+//   * four lanes (g = 0..3) share a query, so a (query, split) pair has 4 partial lists; they share ONE
+//     threshold slot per query (max over their K'-th bests -- still a valid bound).
+// Everything else (LDS-DMA ring, counted vmcnt, split barrier, strict-'>' tie rule, shared thresholds) is
+// scan_kernel_v3's.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "scan_kernel.hpp"
+#include "scan_kernel_v3.hpp"
+
+namespace mips {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int KL, int KS32, int AD>
+__global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int WAVES = 8;
+    constexpr int TN = WAVES * 32;
+    constexpr int STAGES = 3;
+    constexpr int STAGE_BYTES = V3_DB * KS32 * 64; // 32 rows x (32 KS32) k x 2 B
+    constexpr int PIECES = STAGE_BYTES / 1024;
+    constexpr int PPW = PIECES / WAVES;
+    static_assert(PIECES % WAVES == 0, "every wave must issue the same number of DMA pieces");
+    constexpr int STEPS = 2 * KS32; // k32-steps per block (two halves)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15;
+    const int g = lane >> 4;
+
+    const int xcd = blockIdx.x & 7;
+    const int j = blockIdx.x >> 3;
+    const int qt = (xcd % p.qgroups) + p.qgroups * (j % p.qt_per_group);
+    const int split = (xcd / p.qgroups) * p.splits_per_group + j / p.qt_per_group;
+    if (qt >= p.nqt) return;
+
+    const int b0 = split * p.tiles_per_split;
+    int b1 = b0 + p.tiles_per_split;
+    if (b1 > p.ntiles) b1 = p.ntiles;
+    const int nb = b1 > b0 ? b1 - b0 : 0;
+
+    // ---- stationary query fragments: lane holds Q[q0 + 16 n + c][32 s + 8 g .. +8)
+    bf16x8 bq[2][KS32];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const uint16_t* qrow = p.qbuf + ((int64_t)qt * TN + wave * 32 + n * 16 + c) * p.ld + 8 * g;
+#pragma unroll
+        for (int s = 0; s < KS32; ++s) bq[n][s] = *reinterpret_cast<const bf16x8*>(qrow + 32 * s);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int s = 0; s < KS32; ++s) asm volatile("" : "+v"(bq[n][s]));
+#endif
+    }
+
+    float ls[2][KL];
+    int li[2][KL];
+    float thr[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        thr[n] = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < KL; ++i) {
+            ls[n][i] = -INFINITY;
+            li[n][i] = IDX_NONE;
+        }
+    }
+
+    // ---- shared per-query thresholds: ONE slot per query; p.gthr layout [query tile][wave][32 queries].
+    // LDS: 256 B per wave (the DMA writes lane * 4; lanes 32..63 duplicate lanes 0..31).
+    constexpr unsigned THR_AREA = STAGES * STAGE_BYTES;
+    *reinterpret_cast<unsigned*>(smem + THR_AREA + wave * 256 + lane * 4) = 0u;
+    const __amdgpu_buffer_rsrc_t thr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.gthr + (int64_t)qt * TN + wave * 32), 0, 32 * 4, 0x00020000);
+    auto refresh_thresholds = [&]() {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rsrc, (lds_void*)(smem + THR_AREA + wave * 256), 4,
+                                                 (unsigned)((lane & 31) * 4), 0, 0, 16);
+    };
+
+    // ---- LDS-DMA map (as v3): piece pc = slab * 4 + rg, 8 rows x 128 B
+    const unsigned char* docs_b = reinterpret_cast<const unsigned char*>(p.docs);
+    const int64_t row_bytes = (int64_t)p.ld * 2;
+    auto issue_piece = [&](const unsigned char* blk_base, int stage, int i) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void*)blk_base, 0, (int)(V3_DB * row_bytes), 0x00020000);
+        const int pc = wave + WAVES * i;
+        const int slab = pc >> 2, rg = pc & 3;
+        // per-lane source offset, recomputed per piece from the lane id (the kernel has no VGPR to spare):
+        // row lane >> 3 of the piece, chunk slot (lane & 7) ^ ((row >> 1) & 7) = (lane & 7) ^ ((4 rg + (lane >> 4)) & 7)
+        const unsigned ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const unsigned lane_off0 = (ln >> 3) * (unsigned)row_bytes + (((ln & 7u) ^ ((ln >> 4) & 7u)) << 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + stage * STAGE_BYTES + pc * 1024), 16,
+                                                 (rg & 1) ? (lane_off0 ^ 64u) : lane_off0,
+                                                 rg * 8 * (int)row_bytes + slab * 128, 0, 0);
+    };
+    auto issue = [&](const unsigned char* blk_base, int stage) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) issue_piece(blk_base, stage, i);
+    };
+
+    // ---- A-fragment read addresses: row = 16 half + c, chunk 4 (s & 1) + g of slab s >> 1, slot chunk ^ swz
+    const int rd_swz = (c >> 1) & 7;
+    const int rd0 = c * 128 + ((g ^ rd_swz) << 4); // (s & 1) == 0; the odd step is this ^ 64 (chunk + 4)
+
+    // ---- split barrier (see scan_kernel_v3.hpp)
+    const unsigned cnt_lds = (unsigned)(size_t)(lds_void*)(smem + THR_AREA + WAVES * 256);
+    unsigned arrivals_needed = 0;
+    constexpr int PER_BLOCK = PPW + 1;
+    auto arrive = [&]() {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_BLOCK) : "memory");
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(cnt_lds), "v"(1u) : "memory");
+#endif
+    };
+    auto wait_all = [&]() {
+        arrivals_needed += WAVES;
+        for (int spin = 0;; ++spin) {
+            unsigned v = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(cnt_lds) : "memory");
+#endif
+            if (__builtin_amdgcn_readfirstlane(v) >= arrivals_needed) break;
+            if (spin > (1 << 22)) {
+                if (lane == 0) *p.err = 1u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+
+    auto epilogue_half = [&](f32x4 (&acc)[2], int base) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const float mx = fmaxf(fmaxf(acc[n][0], acc[n][1]), fmaxf(acc[n][2], acc[n][3]));
+            if (__ballot(mx > thr[n]) != 0ull) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s = acc[n][r];
+                    if (s > thr[n]) {
+                        list_insert<KL>(ls[n], li[n], s, base + r);
+                        thr[n] = fmaxf(thr[n], ls[n][KL - 1]);
+                    }
+                }
+                if (ls[n][KL - 1] == thr[n]) // the own list sets the bound: publish it (umax makes repeats harmless)
+                    publish_umax(thr_encode(ls[n][KL - 1]),
+                                 (16u * n + (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 15u)) * 4u, thr_rsrc);
+            }
+        }
+    };
+
+    auto block = [&](int blk, int stage, const unsigned char* pbase, int pstage) {
+        const unsigned char* sa = smem + stage * STAGE_BYTES;
+        // flattened step t = half * KS32 + s
+        auto lds_frag = [&](int t) {
+            const int half = t / KS32, s = t % KS32;
+            const int off = half * 2048 + (s >> 1) * 4096 + ((s & 1) ? (rd0 ^ 64) : rd0);
+            return *reinterpret_cast<const bf16x8*>(sa + off);
+        };
+        bf16x8 ar[AD];
+#pragma unroll
+        for (int t = 0; t < AD; ++t) ar[t] = lds_frag(t);
+        refresh_thresholds(); // first VMEM op of the block
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 acc[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[n][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS32; ++s) {
+                const int t = half * KS32 + s;
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[t % AD], bq[0][s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[t % AD], bq[1][s], acc[1], 0, 0, 0);
+                if (t + AD < STEPS) ar[t % AD] = lds_frag(t + AD);
+                if ((t % (STEPS / PPW)) == (STEPS / PPW) / 2) issue_piece(pbase, pstage, t / (STEPS / PPW));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (half == 1) arrive(); // all LDS reads of this block are done; epilogue runs un-synchronised
+            // (everything the epilogue needs is derived HERE, after the chain, to keep the chain's live set small)
+            const unsigned ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            const int base = blk * V3_DB + 16 * half + 4 * (int)(ln >> 4);
+            if (half == 0) { // thresholds of this lane's two queries (an earlier block's DMA, or 0)
+                const unsigned* slot = reinterpret_cast<const unsigned*>(smem + THR_AREA + wave * 256 + (ln & 15u) * 4);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const unsigned key = slot[16 * n];
+                    thr[n] = fmaxf(thr[n], key > 1u ? thr_decode(key - 1u) : -INFINITY);
+                }
+            }
+            if ((int64_t)(blk + 1) * V3_DB > p.ntotal) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if ((int64_t)(base + r) >= p.ntotal) {
+                        acc[0][r] = -INFINITY;
+                        acc[1][r] = -INFINITY;
+                    }
+            }
+            epilogue_half(acc, base);
+        }
+    };
+
+    const unsigned char* first = docs_b + (int64_t)b0 * V3_DB * row_bytes;
+    const unsigned char* last = docs_b + (int64_t)(b1 - 1) * V3_DB * row_bytes;
+    const int64_t blk_bytes = V3_DB * row_bytes;
+    constexpr int AHEAD = STAGES - 1;
+    if (nb > 0) {
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a) { // same operation sequence as steady-state blocks (vmcnt arithmetic)
+            refresh_thresholds();
+            issue(a < nb ? first + a * blk_bytes : last, a);
+        }
+    }
+    const unsigned char* pbase = nb > AHEAD ? first + AHEAD * blk_bytes : last;
+    int stage = 0, pstage = AHEAD;
+    if (tid == 0) *reinterpret_cast<unsigned*>(smem + THR_AREA + WAVES * 256) = 0u;
+    __syncthreads();
+    if (nb > 0) arrive();
+    for (int i = 0; i < nb; ++i) {
+        wait_all();
+        block(b0 + i, stage, pbase, pstage);
+        if (i + AHEAD + 1 < nb) pbase += blk_bytes;
+        stage = stage == STAGES - 1 ? 0 : stage + 1;
+        pstage = pstage == STAGES - 1 ? 0 : pstage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int q = qt * TN + wave * 32 + n * 16 + c;
+        const size_t o = (((size_t)q * p.nsplit + split) * 4 + g) * KL;
+#pragma unroll
+        for (int i = 0; i < KL; ++i) {
+            p.part_s[o + i] = ls[n][i];
+            p.part_i[o + i] = li[n][i];
+        }
+    }
+}
+
+} // namespace mips

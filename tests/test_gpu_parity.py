@@ -742,3 +742,23 @@ def test_np_search_is_inner_product_even_on_an_l2_index(tmp_path):
     assert np.array_equal(i, ei) and np.array_equal(s, es) and (np.diff(s, axis=1) <= 0).all()
     s2, i2 = m.search(m._prepare_query(qs.copy()), k=k)          # the index itself still answers in L2
     assert (np.diff(s2, axis=1) >= 0).all() and np.array_equal(i2, ei)   # same neighbours (IP == augmented L2)
+
+
+def test_experimental_scan_variants_are_bit_identical():
+    """Launch-tuning knobs never change results: the 16x16x32 kernel (variant 4), the 6-entry-list forms
+    (sub 10 / 11), the s_barrier form (sub 3), the generic kernel (variant 1) and other split counts all
+    return the shipped configuration's bits."""
+    n, nq, d, k = 150001, 700, 768, 5
+    ix = ram.MipsIndex(d)
+    ix.add_synthetic(n, row0=0, seed=171, kind=synth.KIND_GAUSS)
+    q = ram.synth_fill(nq, d, 0, 172, synth.KIND_GAUSS)
+    ref_s, ref_i = ix.search(q, k)
+    x = synth.generate(171, 0, n, d, synth.KIND_GAUSS)
+    es, ei = orc.search_exact(q.float().cpu().numpy()[:64], x, k)
+    assert np.array_equal(ref_i[:64].cpu().numpy(), ei) and np.array_equal(ref_s[:64].cpu().numpy(), es)
+    for params in ({"variant": 4}, {"variant": 3, "sub": 10}, {"variant": 3, "sub": 11}, {"variant": 3, "sub": 3},
+                   {"variant": 1}, {"variant": 3, "nsplit": 40}, {"variant": 3, "qgroups": 2}, {"variant": 4, "nsplit": 8}):
+        for name in ("variant", "sub", "nsplit", "qgroups"):
+            ix.set_param(name, params.get(name, 0))
+        s, i = ix.search(q, k)
+        assert torch.equal(i, ref_i) and torch.equal(s, ref_s), params
