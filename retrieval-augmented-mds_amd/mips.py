@@ -221,6 +221,17 @@ class Mips:
         shutil.rmtree(self.embeddings_folder, ignore_errors=True)
         self.embeddings_folder.mkdir(parents=True, exist_ok=True)
 
+    @staticmethod
+    def encode_shard_bounds(n_rows: int, rank: int, num_rank: int):
+        """Row range [start, stop) rank `rank` encodes in the reference's corpus-sharded encoding
+        (`encode_text2`, mips.py:227-229: chunks of N // num_rank + 1 rows, the last rank takes the
+        rest).  The encoders themselves are out of scope; this is the arithmetic a caller needs to hand
+        per-rank embedding shards to `build_index` in the reference's order."""
+        chunk = (n_rows // num_rank) + 1
+        start = min(n_rows, rank * chunk)
+        stop = min(n_rows, (rank + 1) * chunk) if rank + 1 < num_rank else n_rows
+        return start, max(start, stop)
+
     def build_index(self, embeddings=None) -> None:
         """max_norm (mips.py:298-304) -> optional document normalisation for IP (:306-314) ->
         [L2: phi, mips.py:316-324; the augmentation column is implicit in the backend] ->
@@ -234,6 +245,8 @@ class Mips:
         if embeddings is None:
             raise ValueError("build_index needs the [N, d] embedding matrix")
         dev = f"cuda:{_lib.require_gpu(self.args.mips_device)}"
+        if isinstance(embeddings, (list, tuple)):  # per-rank shards in rank order (mips.py:292-295 concatenates them)
+            embeddings = torch.cat([torch.as_tensor(e).to(dev, dtype=torch.float32) for e in embeddings], dim=0)
         x = torch.as_tensor(embeddings)
         if isinstance(self.args.mips_db_max_size, int):
             x = x[: self.args.mips_db_max_size]

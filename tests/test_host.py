@@ -257,3 +257,16 @@ def test_sharded_search_two_ranks_gloo(world, n):
     ret = mgr.dict()
     mp.spawn(_gloo_worker, args=(world, port, n, 5, 64, 4, ret), nprocs=world, join=True)
     assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_encode_shard_bounds_follow_the_reference_chunking():
+    # mips.py:227-229: chunck_size = N // num_rank + 1; stop = (rank + 1) * chunck_size if rank + 1 < num_rank else N
+    for n in (10, 1003, 4096):
+        for w in (1, 2, 3, 8):
+            spans = [ram.Mips.encode_shard_bounds(n, r, w) for r in range(w)]
+            chunk = n // w + 1
+            for r, (a, b) in enumerate(spans):
+                exp_stop = (r + 1) * chunk if r + 1 < w else n
+                assert (a, b) == (min(n, r * chunk), max(min(n, r * chunk), min(n, exp_stop)))
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert sum(b - a for a, b in spans) == n
