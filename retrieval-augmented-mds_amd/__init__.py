@@ -8,8 +8,8 @@ Everything numeric runs in libmips_hip.so (hand-written HIP for gfx950, csrc/); 
 fallback.  See DESIGN.md and include/mips_hip.h.
 """
 from . import _lib
-from ._lib import (DTYPE_BF16, DTYPE_F32, MAX_K, METRIC_IP, METRIC_L2, SYNTH_GAUSS, SYNTH_LATTICE,
-                   SYNTH_LATTICE_FP8, build)
+from ._lib import (DTYPE_BF16, DTYPE_F32, MAX_K, METRIC_IP, METRIC_L2, SEED_DOCS, SEED_QUERIES, SYNTH_GAUSS,
+                   SYNTH_LATTICE, SYNTH_LATTICE_FP8, build)
 from .index import (MipsIndex, cosine_rescore, filter_ignore, l2_normalize_, merge_topk, merge_topk_packed,
                     rows_max_sumsq, synth_fill)
 from .mips import (KnowledgeBase, Mips, MipsArgs, MipsModelOutput, augment_xb, augment_xq, get_phi,

@@ -25,6 +25,7 @@ DTYPE_F32, DTYPE_BF16, DTYPE_FP8_E4M3 = 0, 1, 2
 METRIC_IP, METRIC_L2 = 0, 1
 Q_DEVICE, OUT_DEVICE, OUT_PACKED, FORCE_IP = 1, 2, 4, 8
 SYNTH_LATTICE, SYNTH_GAUSS, SYNTH_LATTICE_FP8 = 0, 1, 2
+SEED_DOCS, SEED_QUERIES = 0xD0C5, 0x0E21  # fixed seeds of the synthetic workloads
 MAX_K = 29
 
 _lock = threading.Lock()

@@ -4,7 +4,6 @@ import argparse, json, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import retrieval_augmented_mds_amd as ram
-from oracle import synth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("variants", nargs="+")
@@ -16,8 +15,8 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=5)
 a = ap.parse_args()
 ix = ram.MipsIndex(a.dim)
-ix.add_synthetic(a.rows, 0, synth.SEED_DOCS, synth.KIND_GAUSS)
-q = ram.synth_fill(a.queries, a.dim, 0, synth.SEED_QUERIES, synth.KIND_GAUSS)
+ix.add_synthetic(a.rows, 0, ram.SEED_DOCS, ram.SYNTH_GAUSS)
+q = ram.synth_fill(a.queries, a.dim, 0, ram.SEED_QUERIES, ram.SYNTH_GAUSS)
 ref = None
 res = {v: [] for v in a.variants}
 for r in range(a.rounds):

@@ -3,7 +3,6 @@ import argparse, json, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import retrieval_augmented_mds_amd as ram
-from oracle import synth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=1 << 20)
@@ -17,11 +16,11 @@ ix = ram.MipsIndex(a.dim, dtype=a.dtype)
 esz = 1 if a.dtype != "bf16" else 2
 t0 = time.perf_counter()
 ix.reserve(a.rows)
-ix.add_synthetic(a.rows, 0, synth.SEED_DOCS, synth.KIND_GAUSS)
+ix.add_synthetic(a.rows, 0, ram.SEED_DOCS, ram.SYNTH_GAUSS)
 torch.cuda.synchronize()
 print(f"index {a.rows}x{a.dim}: generated in {time.perf_counter() - t0:.2f} s", flush=True)
 for nq in a.queries:
-    q = ram.synth_fill(nq, a.dim, 0, synth.SEED_QUERIES, synth.KIND_GAUSS)
+    q = ram.synth_fill(nq, a.dim, 0, ram.SEED_QUERIES, ram.SYNTH_GAUSS)
     for _ in range(2): ix.search(q, a.k)
     torch.cuda.synchronize(); ix.scan_timing(reset=True)
     t0 = time.perf_counter()
