@@ -166,6 +166,14 @@ int mips_filter_ignore(const float* scores, const int64_t* idx, const int64_t* i
 int mips_cosine_rescore(const void* query, const void* cls, int dtype, int64_t b, int k, int64_t d,
                         float* out, int device, void* hip_stream);
 
+/* The same re-score fused with the hook's memory_bias broadcast (retriever_generator.py:188-192:
+ * mips_scores.unsqueeze(-1).expand(-1, -1, memory_seq_len).reshape(b, -1)): additionally writes
+ * memory_bias[b][j * memory_seq_len + t] = out[b][j] for t < memory_seq_len (DEVICE float32
+ * [b, k * memory_seq_len]).  memory_seq_len == 0 skips the broadcast. */
+int mips_cosine_rescore_bias(const void* query, const void* cls, int dtype, int64_t b, int k, int64_t d,
+                             float* out, int64_t memory_seq_len, float* memory_bias, int device,
+                             void* hip_stream);
+
 /* In-place row L2 normalisation of a DEVICE float32 matrix [n, d].  Replaces
  * faiss.normalize_L2 behind Mips.l2_normalization (sotasum/mips.py:521-525), used for documents
  * at build time (mips.py:306-314, 358-361) and for queries (mips.py:369-370).  Rows of norm 0 are

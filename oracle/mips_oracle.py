@@ -351,3 +351,10 @@ def cosine_rescore(query, mips_cls):
     mips_norms = torch.norm(mips_cls, dim=2, keepdim=True)
     mips_scores = mips_scores / (query_norms * mips_norms).squeeze(2)
     return mips_scores
+
+
+def memory_bias(mips_scores, memory_seq_len: int):
+    """sotasum/retriever_generator.py:188-192: every hit's score repeated over its memory tokens,
+    [B,k] -> [B, k * memory_seq_len]."""
+    b = mips_scores.shape[0]
+    return mips_scores.unsqueeze(-1).expand(-1, -1, memory_seq_len).reshape(b, -1)

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE (oracle side) -- deterministic counter-based synthetic data.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
-The product generates the same values on the device (csrc/mips_synth.hip); a GPU
+The product generates the same values on the device (csrc/aux_kernels.hpp::synth_fill_kernel); a GPU
 test checks that both generators agree bit for bit, so host and device can each
 regenerate the BASELINE.json workloads without moving the
 index over PCIe.

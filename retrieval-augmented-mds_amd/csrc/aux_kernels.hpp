@@ -562,7 +562,7 @@ __device__ __forceinline__ float load_as_f32<uint16_t>(const uint16_t* p, int64_
 
 template <typename T>
 __global__ __launch_bounds__(256) void cosine_rescore_kernel(const T* query, const T* cls, int64_t pairs, int k, int d,
-                                                             float* out) {
+                                                             float* out, int64_t mem_len, float* bias) {
     const int64_t pr = blockIdx.x * 4ll + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (pr >= pairs) return;
@@ -581,7 +581,12 @@ __global__ __launch_bounds__(256) void cosine_rescore_kernel(const T* query, con
         qq += __shfl_xor(qq, off);
         cc += __shfl_xor(cc, off);
     }
-    if (lane == 0) out[pr] = qc / (sqrtf(qq) * sqrtf(cc));
+    const float cosv = qc / (sqrtf(qq) * sqrtf(cc));
+    if (lane == 0) out[pr] = cosv;
+    // memory_bias of the hook (retriever_generator.py:188-192): the score of hit (b, j) repeated over
+    // the mem_len tokens of that hit, laid out [b, k * mem_len] -> pair pr owns one contiguous run
+    if (bias != nullptr)
+        for (int64_t t = lane; t < mem_len; t += 64) bias[pr * mem_len + t] = cosv;
 }
 
 __global__ void fill_empty_kernel(float* out_s, int64_t* out_i, int64_t* out_packed, int64_t total, int metric) {

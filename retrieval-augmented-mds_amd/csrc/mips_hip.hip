@@ -772,22 +772,34 @@ int mips_filter_ignore(const float* scores, const int64_t* idx, const int64_t* i
     return MIPS_OK;
 }
 
-int mips_cosine_rescore(const void* query, const void* cls, int dtype, int64_t b, int k, int64_t d, float* out, int device,
-                        void* hip_stream) {
-    if (b < 0 || k < 0 || d <= 0) return fail(MIPS_E_INVALID, "mips_cosine_rescore: bad sizes");
-    if (dtype != MIPS_DTYPE_F32 && dtype != MIPS_DTYPE_BF16) return fail(MIPS_E_INVALID, "mips_cosine_rescore: dtype must be F32 or BF16");
+static int cosine_rescore_impl(const char* who, const void* query, const void* cls, int dtype, int64_t b, int k, int64_t d,
+                               float* out, int64_t mem_len, float* bias, int device, void* hip_stream) {
+    if (b < 0 || k < 0 || d <= 0 || mem_len < 0) return fail(MIPS_E_INVALID, "%s: bad sizes", who);
+    if (dtype != MIPS_DTYPE_F32 && dtype != MIPS_DTYPE_BF16) return fail(MIPS_E_INVALID, "%s: dtype must be F32 or BF16", who);
     if (b == 0 || k == 0) return MIPS_OK;
-    if (!query || !cls || !out) return fail(MIPS_E_INVALID, "mips_cosine_rescore: NULL buffer");
+    if (!query || !cls || !out || (mem_len > 0 && !bias)) return fail(MIPS_E_INVALID, "%s: NULL buffer", who);
     DeviceGuard g(device);
     if (!g.ok) return fail(MIPS_E_HIP, "hipSetDevice(%d) failed", device);
     const int64_t pairs = b * k;
     const int grid = (int)((pairs + 3) / 4);
+    float* bias_arg = mem_len > 0 ? bias : nullptr;
     if (dtype == MIPS_DTYPE_F32)
-        mips::cosine_rescore_kernel<float><<<grid, 256, 0, (hipStream_t)hip_stream>>>((const float*)query, (const float*)cls, pairs, k, (int)d, out);
+        mips::cosine_rescore_kernel<float><<<grid, 256, 0, (hipStream_t)hip_stream>>>((const float*)query, (const float*)cls, pairs, k, (int)d, out, mem_len, bias_arg);
     else
-        mips::cosine_rescore_kernel<uint16_t><<<grid, 256, 0, (hipStream_t)hip_stream>>>((const uint16_t*)query, (const uint16_t*)cls, pairs, k, (int)d, out);
+        mips::cosine_rescore_kernel<uint16_t><<<grid, 256, 0, (hipStream_t)hip_stream>>>((const uint16_t*)query, (const uint16_t*)cls, pairs, k, (int)d, out, mem_len, bias_arg);
     HIP_TRY(hipGetLastError());
     return MIPS_OK;
+}
+
+int mips_cosine_rescore(const void* query, const void* cls, int dtype, int64_t b, int k, int64_t d, float* out, int device,
+                        void* hip_stream) {
+    return cosine_rescore_impl("mips_cosine_rescore", query, cls, dtype, b, k, d, out, 0, nullptr, device, hip_stream);
+}
+
+int mips_cosine_rescore_bias(const void* query, const void* cls, int dtype, int64_t b, int k, int64_t d, float* out,
+                             int64_t memory_seq_len, float* memory_bias, int device, void* hip_stream) {
+    return cosine_rescore_impl("mips_cosine_rescore_bias", query, cls, dtype, b, k, d, out, memory_seq_len, memory_bias, device,
+                               hip_stream);
 }
 
 int mips_l2_normalize(float* x_device, int64_t n, int64_t d, int device, void* hip_stream) {

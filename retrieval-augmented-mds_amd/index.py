@@ -358,9 +358,11 @@ def filter_ignore(scores, idx, ignore, k: int):
     return out_s, out_i
 
 
-def cosine_rescore(query, mips_cls):
+def cosine_rescore(query, mips_cls, memory_seq_len: int = 0):
     """retriever_generator.py:158-172 on the device: query [B, 1, d] or [B, d], mips_cls [B, k, d]
-    (CUDA float32 or bfloat16) -> float32 [B, k] = q . c / (|q| |c|)."""
+    (CUDA float32 or bfloat16) -> float32 [B, k] = q . c / (|q| |c|).  With memory_seq_len > 0 the
+    same launch also writes the hook's memory_bias (retriever_generator.py:188-192), float32
+    [B, k * memory_seq_len], and (scores, memory_bias) is returned."""
     import torch
 
     lib = _lib.load()
@@ -369,6 +371,8 @@ def cosine_rescore(query, mips_cls):
     b, k, d = mips_cls.shape
     if query.shape != (b, d) or not (query.is_cuda and mips_cls.is_cuda):
         raise ValueError("cosine_rescore: expected CUDA query [B,(1,)d] and mips_cls [B,k,d]")
+    if memory_seq_len < 0:
+        raise ValueError("cosine_rescore: memory_seq_len must be >= 0")
     if mips_cls.dtype == torch.bfloat16 and query.dtype == torch.bfloat16:
         code = _lib.DTYPE_BF16
     else:
@@ -376,6 +380,12 @@ def cosine_rescore(query, mips_cls):
     query, mips_cls = query.contiguous(), mips_cls.contiguous()
     dev = query.device.index
     out = torch.empty((b, k), dtype=torch.float32, device=query.device)
-    _lib.check(lib.mips_cosine_rescore(query.data_ptr(), mips_cls.data_ptr(), code, b, k, d, out.data_ptr(), dev,
-                                       _stream_handle(dev)), "mips_cosine_rescore")
-    return out
+    if memory_seq_len == 0:
+        _lib.check(lib.mips_cosine_rescore(query.data_ptr(), mips_cls.data_ptr(), code, b, k, d, out.data_ptr(), dev,
+                                           _stream_handle(dev)), "mips_cosine_rescore")
+        return out
+    bias = torch.empty((b, k * memory_seq_len), dtype=torch.float32, device=query.device)
+    _lib.check(lib.mips_cosine_rescore_bias(query.data_ptr(), mips_cls.data_ptr(), code, b, k, d, out.data_ptr(),
+                                            memory_seq_len, bias.data_ptr(), dev, _stream_handle(dev)),
+               "mips_cosine_rescore_bias")
+    return out, bias

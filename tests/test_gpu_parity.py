@@ -532,9 +532,11 @@ def test_cosine_rescore_kernel():
     out16 = ram.cosine_rescore(q.bfloat16(), c.bfloat16())
     ref16 = orc.cosine_rescore(q.bfloat16().float().cpu(), c.bfloat16().float().cpu())
     assert torch.allclose(out16.cpu(), ref16, atol=2e-6, rtol=1e-5)
-    # memory_bias expansion of the hook (retriever_generator.py:188-192) stays a view op
-    bias = out.unsqueeze(-1).expand(-1, -1, 16).reshape(7, -1)
-    assert bias.shape == (7, 80) and torch.equal(bias[:, 16], out[:, 1])
+    # memory_bias of the hook (retriever_generator.py:188-192) written by the same launch
+    for mem_len, qq, cc in ((16, q, c), (131, q.bfloat16(), c.bfloat16())):
+        sc, bias = ram.cosine_rescore(qq, cc, memory_seq_len=mem_len)
+        assert torch.equal(sc, ram.cosine_rescore(qq, cc))
+        assert bias.shape == (7, 5 * mem_len) and torch.equal(bias.cpu(), orc.memory_bias(sc.cpu(), mem_len))
 
 
 # ------------------------------------------------------------------ fp8 e4m3 index (BASELINE config 5)
