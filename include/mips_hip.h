@@ -16,8 +16,11 @@
  *     HBM and its scratch.  Work is enqueued on the HIP stream passed in (NULL = the
  *     default stream); there is no hidden device-wide synchronisation.  Calls that take
  *     HOST output buffers synchronise that stream before returning.
- *   - one index lives on one GPU.  Concurrent calls on one index must be serialised by
- *     the caller (the Python wrapper holds a lock).
+ *   - one index lives on one GPU.  Concurrent calls on one index (from several host
+ *     threads) must be serialised by the caller (the Python wrapper holds a lock).  Calls
+ *     issued on different streams are ordered by the library: a call waits, on its own
+ *     stream, for an event recorded at the end of the previous call on that index, so
+ *     the shared scratch is never used by two in-flight searches.
  *   - ties: the lowest document index wins (the reference leaves ties undefined).
  *   - padding (FAISS IndexFlat convention): when k > ntotal the tail of every row is
  *     idx = -1, score = -inf (inner product) or +inf (L2).

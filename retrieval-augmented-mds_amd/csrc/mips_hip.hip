@@ -117,40 +117,69 @@ struct mips_index {
     hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
     int ev_count = 0; // pairs recorded since the last reset (saturates at kEvRing)
     int ev_next = 0;
+    // The scratch buffers are shared by every call on this index.  Calls on ONE stream are ordered by the
+    // stream; a call arriving on another stream first waits for `busy`, recorded at the end of the last call.
+    hipEvent_t busy = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
 };
 
 namespace {
 
-int grow(mips_index* ix, int64_t need_rows, hipStream_t st) {
+// Orders the calls on one index across streams (see mips_index::busy).  The guard's destructor records the
+// event on every exit path, so work a failed call already enqueued is covered as well.
+struct StreamOrder {
+    mips_index* ix;
+    hipStream_t st;
+    bool ok = true;
+    StreamOrder(mips_index* ix_, hipStream_t st_) : ix(ix_), st(st_) {
+        if (ix->has_last && ix->last_stream != st) ok = hipStreamWaitEvent(st, ix->busy, 0) == hipSuccess;
+    }
+    ~StreamOrder() {
+        if (hipEventRecord(ix->busy, st) == hipSuccess) {
+            ix->last_stream = st;
+            ix->has_last = true;
+        }
+    }
+};
+#define ORDER_ON(ix, st)             \
+    StreamOrder order_guard(ix, st); \
+    if (!order_guard.ok) return fail(MIPS_E_HIP, "hipStreamWaitEvent failed")
+
+// exact = false: geometric growth for repeated adds; true: mips_index_reserve's exact reservation
+int grow(mips_index* ix, int64_t need_rows, hipStream_t st, bool exact = false) {
     if (need_rows <= ix->capacity) return MIPS_OK;
-    int64_t cap = std::max<int64_t>(need_rows, ix->capacity + ix->capacity / 2);
+    int64_t cap = exact ? need_rows : std::max<int64_t>(need_rows, ix->capacity + ix->capacity / 2);
     cap = round_up(cap, kRowAlign);
     uint8_t* fresh = nullptr;
+    float* fresh32 = nullptr;
     const size_t row_bytes = (size_t)ix->ld * ix->esize;
     const size_t bytes = (size_t)cap * row_bytes;
+    const size_t b32 = (size_t)cap * ix->plane * sizeof(float);
     hipError_t e = hipMalloc((void**)&fresh, bytes);
     if (e != hipSuccess) return fail(MIPS_E_NOMEM, "hipMalloc(%zu) for the index failed: %s", bytes, hipGetErrorString(e));
-    const size_t used = (size_t)ix->ntotal * row_bytes;
-    if (used) HIP_TRY(hipMemcpyAsync(fresh, ix->rows, used, hipMemcpyDeviceToDevice, st));
-    // rows past ntotal are read by the last (ragged) tile: keep them defined
-    HIP_TRY(hipMemsetAsync(fresh + used, 0, bytes - used, st));
-    float* fresh32 = nullptr;
     if (ix->plane > 0) {
-        const size_t b32 = (size_t)cap * ix->plane * sizeof(float);
         e = hipMalloc((void**)&fresh32, b32);
         if (e != hipSuccess) {
             (void)hipFree(fresh);
             return fail(MIPS_E_NOMEM, "hipMalloc(%zu) for the fp32 rows failed: %s", b32, hipGetErrorString(e));
         }
-        const size_t u32 = (size_t)ix->ntotal * ix->plane * sizeof(float);
-        if (u32) HIP_TRY(hipMemcpyAsync(fresh32, ix->rows_f32, u32, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemsetAsync((char*)fresh32 + u32, 0, b32 - u32, st));
     }
-    if (ix->rows) {
-        HIP_TRY(hipStreamSynchronize(st));
-        (void)hipFree(ix->rows);
-        if (ix->rows_f32) (void)hipFree(ix->rows_f32);
+    // copy the rows in use; rows past ntotal are read by the last (ragged) tile: keep them defined
+    const size_t used = (size_t)ix->ntotal * row_bytes;
+    const size_t u32 = (size_t)ix->ntotal * ix->plane * sizeof(float);
+    if (used) e = hipMemcpyAsync(fresh, ix->rows, used, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(fresh + used, 0, bytes - used, st);
+    if (e == hipSuccess && fresh32 && u32) e = hipMemcpyAsync(fresh32, ix->rows_f32, u32, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && fresh32) e = hipMemsetAsync((char*)fresh32 + u32, 0, b32 - u32, st);
+    if (e == hipSuccess && ix->rows) e = hipStreamSynchronize(st); // the old storage is freed below
+    if (e != hipSuccess) {
+        (void)hipFree(fresh);
+        if (fresh32) (void)hipFree(fresh32);
+        return fail(MIPS_E_HIP, "growing the index to %lld rows failed: %s", (long long)cap, hipGetErrorString(e));
     }
+    if (ix->rows) (void)hipFree(ix->rows);
+    if (ix->rows_f32) (void)hipFree(ix->rows_f32);
     ix->rows = fresh;
     ix->rows_f32 = fresh32;
     ix->capacity = cap;
@@ -491,6 +520,10 @@ int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, 
             mips_index_destroy(ix);
             return fail(MIPS_E_HIP, "hipEventCreate failed");
         }
+    if (hipEventCreateWithFlags(&ix->busy, hipEventDisableTiming) != hipSuccess) {
+        mips_index_destroy(ix);
+        return fail(MIPS_E_HIP, "hipEventCreate failed");
+    }
     *out = ix;
     return MIPS_OK;
 }
@@ -515,42 +548,17 @@ int mips_index_destroy(mips_index_t* ix) {
         if (ix->ev0[e]) (void)hipEventDestroy(ix->ev0[e]);
         if (ix->ev1[e]) (void)hipEventDestroy(ix->ev1[e]);
     }
+    if (ix->busy) (void)hipEventDestroy(ix->busy);
     delete ix;
     return MIPS_OK;
 }
 
 int mips_index_reserve(mips_index_t* ix, int64_t n) {
     if (!ix || n < 0) return fail(MIPS_E_INVALID, "mips_index_reserve: bad argument");
+    if (n > (int64_t)0x7fffff00) return fail(MIPS_E_UNSUPPORTED, "mips_index_reserve: more than 2^31 rows on one GPU");
     DeviceGuard g(ix->device);
-    if (n <= ix->capacity) return MIPS_OK;
-    // exact reservation (no geometric slack)
-    int64_t cap = round_up(n, kRowAlign);
-    uint8_t* fresh = nullptr;
-    const size_t row_bytes = (size_t)ix->ld * ix->esize;
-    const size_t bytes = (size_t)cap * row_bytes;
-    hipError_t e = hipMalloc((void**)&fresh, bytes);
-    if (e != hipSuccess) return fail(MIPS_E_NOMEM, "hipMalloc(%zu) for the index failed: %s", bytes, hipGetErrorString(e));
-    const size_t used = (size_t)ix->ntotal * row_bytes;
-    if (used) HIP_TRY(hipMemcpy(fresh, ix->rows, used, hipMemcpyDeviceToDevice));
-    HIP_TRY(hipMemset(fresh + used, 0, bytes - used));
-    if (ix->plane > 0) {
-        float* fresh32 = nullptr;
-        const size_t b32 = (size_t)cap * ix->plane * sizeof(float);
-        e = hipMalloc((void**)&fresh32, b32);
-        if (e != hipSuccess) {
-            (void)hipFree(fresh);
-            return fail(MIPS_E_NOMEM, "hipMalloc(%zu) for the fp32 rows failed: %s", b32, hipGetErrorString(e));
-        }
-        const size_t u32 = (size_t)ix->ntotal * ix->plane * sizeof(float);
-        if (u32) HIP_TRY(hipMemcpy(fresh32, ix->rows_f32, u32, hipMemcpyDeviceToDevice));
-        HIP_TRY(hipMemset((char*)fresh32 + u32, 0, b32 - u32));
-        if (ix->rows_f32) (void)hipFree(ix->rows_f32);
-        ix->rows_f32 = fresh32;
-    }
-    if (ix->rows) (void)hipFree(ix->rows);
-    ix->rows = fresh;
-    ix->capacity = cap;
-    return MIPS_OK;
+    ORDER_ON(ix, nullptr);
+    return grow(ix, n, nullptr, /*exact=*/true);
 }
 
 int mips_index_add(mips_index_t* ix, const void* rows, int64_t n, int src_dtype, int src_is_device, void* hip_stream) {
@@ -562,6 +570,7 @@ int mips_index_add(mips_index_t* ix, const void* rows, int64_t n, int src_dtype,
     if (ix->ntotal + n > (int64_t)0x7fffff00) return fail(MIPS_E_UNSUPPORTED, "mips_index_add: more than 2^31 rows on one GPU");
     DeviceGuard g(ix->device);
     hipStream_t st = (hipStream_t)hip_stream;
+    ORDER_ON(ix, st);
     int rc = grow(ix, ix->ntotal + n, st);
     if (rc) return rc;
     rc = convert_into(ix, rows, n, src_dtype, src_is_device, ix->rows + (size_t)ix->ntotal * ix->ld * ix->esize, st,
@@ -587,6 +596,7 @@ int mips_index_metric(const mips_index_t* ix) { return ix ? ix->metric : -1; }
 int mips_index_phi(mips_index_t* ix, double* out_phi, void* hip_stream) {
     if (!ix || !out_phi) return fail(MIPS_E_INVALID, "mips_index_phi: bad argument");
     DeviceGuard g(ix->device);
+    ORDER_ON(ix, (hipStream_t)hip_stream);
     int rc = compute_phi(ix, (hipStream_t)hip_stream);
     if (rc) return rc;
     *out_phi = ix->phi;
@@ -608,6 +618,7 @@ int mips_index_read_rows(mips_index_t* ix, int64_t row0, int64_t n, void* out_ho
     if (n == 0) return MIPS_OK;
     DeviceGuard g(ix->device);
     hipStream_t st = (hipStream_t)hip_stream;
+    ORDER_ON(ix, st);
     if (ix->plane > 0) { // fp32-exact mode: the fp32 originals
         HIP_TRY(hipMemcpy2DAsync(out_host_u16, (size_t)ix->d * 4, ix->rows_f32 + (size_t)row0 * ix->plane, (size_t)ix->plane * 4,
                                  (size_t)ix->d * 4, (size_t)n, hipMemcpyDeviceToHost, st));
@@ -627,6 +638,7 @@ int mips_index_add_synthetic(mips_index_t* ix, int64_t n, int64_t row0, uint64_t
     if (ix->ntotal + n > (int64_t)0x7fffff00) return fail(MIPS_E_UNSUPPORTED, "more than 2^31 rows on one GPU");
     DeviceGuard g(ix->device);
     hipStream_t st = (hipStream_t)hip_stream;
+    ORDER_ON(ix, st);
     int rc = grow(ix, ix->ntotal + n, st);
     if (rc) return rc;
     if (ix->plane > 0) {
@@ -674,6 +686,7 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
     if (nq > (1 << 24)) return fail(MIPS_E_UNSUPPORTED, "mips_search: more than 2^24 queries in one call");
     DeviceGuard g(ix->device);
     hipStream_t st = (hipStream_t)hip_stream;
+    ORDER_ON(ix, st);
     const bool out_dev = (flags & MIPS_OUT_DEVICE) != 0;
     const bool packed = (flags & MIPS_OUT_PACKED) != 0;
     ix->call_metric = (flags & MIPS_FORCE_IP) ? MIPS_METRIC_IP : ix->metric;

@@ -447,6 +447,27 @@ def test_tiny_splits_cold_start_stress():
             assert np.array_equal(i, ei) and np.array_equal(s, es)
 
 
+def test_searches_on_two_streams_do_not_share_scratch_in_flight():
+    """include/mips_hip.h conventions: calls on one index issued on different streams are ordered by the
+    library (event recorded after every call), so back-to-back device-output searches on two streams with
+    no synchronisation in between return what the same searches return one at a time."""
+    ix = ram.MipsIndex(768)
+    ix.add_synthetic(200000, 0, synth.SEED_DOCS, synth.KIND_GAUSS)
+    qa = ram.synth_fill(512, 768, 0, 11, synth.KIND_GAUSS)
+    qb = ram.synth_fill(512, 768, 0, 12, synth.KIND_GAUSS)
+    ra, rb = ix.search(qa, 5), ix.search(qb, 5)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(10):
+        with torch.cuda.stream(s1):
+            a = ix.search(qa, 5)
+        with torch.cuda.stream(s2):
+            b = ix.search(qb, 5)
+        torch.cuda.synchronize()
+        assert torch.equal(a[1], ra[1]) and torch.equal(a[0], ra[0])
+        assert torch.equal(b[1], rb[1]) and torch.equal(b[0], rb[0])
+
+
 def _big_properties(n, d, nq, k, plant_stride):
     """Size-independent checks for indexes too large for the oracle: sortedness (ties by index), planted
     duplicates retrieved as their own nearest neighbour, returned scores == canonical re-score of the

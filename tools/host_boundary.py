@@ -1,0 +1,33 @@
+"""PCIe-inclusive rates of the drop-in call shape (GPU box): NumPy float32 queries in, NumPy results out,
+exactly what `faiss_index.search(queries, k)` hands over at sotasum/mips.py:383-386.  Not bench.py's `value`
+(that one starts with the queries resident in HBM); DESIGN.md section 5 quotes these numbers.
+usage: python tools/host_boundary.py"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import retrieval_augmented_mds_amd as ram
+
+
+def timed(fn, iters):
+    fn(); torch.cuda.synchronize()
+    t = []
+    for _ in range(iters):
+        t0 = time.perf_counter(); fn(); t.append(time.perf_counter() - t0)
+    return float(np.median(t)), float(np.min(t))
+
+
+out = []
+for rows, nq, iters, name in ((1 << 20, 4096, 20, "BASELINE config 2"), (10000, 8, 200, "BASELINE config 1 shape (bf16 storage)")):
+    ix = ram.MipsIndex(768)
+    ix.add_synthetic(rows, 0, ram.SEED_DOCS, ram.SYNTH_GAUSS)
+    q_dev = ram.synth_fill(nq, 768, 0, ram.SEED_QUERIES, ram.SYNTH_GAUSS)
+    q_host = q_dev.float().cpu().numpy()
+    med_h, min_h = timed(lambda: ix.search(q_host, 5), iters)
+
+    def dev_call():
+        ix.search(q_dev, 5); torch.cuda.synchronize()
+    med_d, min_d = timed(dev_call, iters)
+    out.append({"workload": f"{name}: {rows}x768 bf16 index, Q={nq}, k=5",
+                "host_numpy_f32_in_out_ms": {"median": med_h * 1e3, "min": min_h * 1e3}, "host_queries_per_s": nq / med_h,
+                "device_resident_ms": {"median": med_d * 1e3, "min": min_d * 1e3}, "device_queries_per_s": nq / med_d})
+print(json.dumps(out, indent=1))
