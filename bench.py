@@ -169,10 +169,16 @@ def main():
             traffic_src = t["source"]
     except Exception:
         pass
+    # the instance mips_search dispatches to for this shape (mips_hip.hip::launch_search); other shapes run
+    # other instances of the same kernels, named in the rocprofv3 summary of that run
+    if (d, k) == (768, 5) and nq > 256:
+        kernel_name = "mips::scan_kernel_f8<8, 768, 2>" if f8 else "mips::scan_kernel_v3<8, 48, 1, 2, true, 0, 2, 8, 3, true, false, 8>"
+    else:
+        kernel_name = "mips::scan_kernel_f8<...>" if f8 else "mips::scan_kernel_v3<...> / mips::scan_kernel<...> (see DESIGN.md section 4)"
     roofline = {
         "bound": "mfma", "achieved": ach_tflops, "peak": PEAK_FP8_TFLOPS if f8 else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": ach_tflops / (PEAK_FP8_TFLOPS if f8 else PEAK_BF16_TFLOPS), "traffic": traffic, "traffic_source": traffic_src,
-        "kernel": "mips::scan_kernel_f8<8, 768, 2>" if f8 else "mips::scan_kernel_v3<8, 48, 1, 2, true, 0, true, 8, 3, true, false>",
+        "kernel": kernel_name,
         "kernel_ms": scan_ms,
         "launches_timed": scan_launches,
         "flops_per_launch": flops, "bytes_per_launch": bytes_,

@@ -351,12 +351,14 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     a.err = nullptr;
     ix->err_off = 0;
     if (variant == 3) {
-        rc = ix->gthr.ensure(((size_t)nq_pad * 2 + 4) * sizeof(unsigned)); // one slot per (query, lane half) + error word
+        // shared insert bounds: 8 class words per query (2 lane-half words in the older layouts) + error word
+        const size_t thr_words = (size_t)nq_pad * 8;
+        rc = ix->gthr.ensure((thr_words + 4) * sizeof(unsigned));
         if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(ix->gthr.p, 0, ((size_t)nq_pad * 2 + 4) * sizeof(unsigned), st));
+        HIP_TRY(hipMemsetAsync(ix->gthr.p, 0, (thr_words + 4) * sizeof(unsigned), st));
         a.gthr = (unsigned*)ix->gthr.p;
-        a.err = a.gthr + (size_t)nq_pad * 2;
-        ix->err_off = (size_t)nq_pad * 2;
+        a.err = a.gthr + thr_words;
+        ix->err_off = thr_words;
     }
 
     const int grid = qt_per_group * qgroups * nsplit;
@@ -374,7 +376,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             fa.docs = ix->rows;
             fa.qbuf = (const uint8_t*)ix->qbuf.p;
             fa.c = a;
-            const int lds = 3 * mips::V3_DB * ix->ld + 8 * 256 + 16;
+            const int lds = 3 * mips::V3_DB * ix->ld + 8 * 1024 + 1024 + 16; // ring + threshold words + dump area + arrival counter
             auto gof8 = [&](auto kern) -> int {
                 HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
                 HIP_TRY(hipEventRecord(ix->ev0[slot], st));
@@ -395,7 +397,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         mips::scan_kernel<KL><<<grid, mips::SCAN_THREADS, mips::SCAN_LDS_BYTES, st>>>(a);
     } else if constexpr (KL != 8) {
         // 4-wave configuration, 3-stage ring (d <= 768: 3 x 48 KiB)
-        const int lds = 3 * mips::V3_DB * ix->ld * 2 + 4 * 256 + 16;
+        const int lds = 3 * mips::V3_DB * ix->ld * 2 + 4 * 1024 + 1024 + 16;
         auto go4 = [&](auto kern) -> int {
             HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             HIP_TRY(hipEventRecord(ix->ev0[slot], st));
@@ -403,12 +405,12 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             return MIPS_OK;
         };
         int rc2;
-        if (ix->ld == 768) rc2 = go4(mips::scan_kernel_v3<KL, 48, 1, 4, true, 0, true, 4, 3>);
-        else if (ix->ld == 512) rc2 = go4(mips::scan_kernel_v3<KL, 32, 1, 4, true, 0, true, 4, 3>);
-        else rc2 = go4(mips::scan_kernel_v3<KL, 16, 1, 4, true, 0, true, 4, 3>);
+        if (ix->ld == 768) rc2 = go4(mips::scan_kernel_v3<KL, 48, 1, 4, true, 0, 2, 4, 3>);
+        else if (ix->ld == 512) rc2 = go4(mips::scan_kernel_v3<KL, 32, 1, 4, true, 0, 2, 4, 3>);
+        else rc2 = go4(mips::scan_kernel_v3<KL, 16, 1, 4, true, 0, 2, 4, 3>);
         if (rc2) return rc2;
     } else {
-        const int lds = (v3_waves == 4 ? 2 : 3) * mips::V3_DB * ix->ld * 2 + v3_waves * 256 + 16; // ring + threshold slots + arrival counter
+        const int lds = (v3_waves == 4 ? 2 : 3) * mips::V3_DB * ix->ld * 2 + v3_waves * 1024 + 1024 + 16; // ring + threshold words + dump area + arrival counter
         const int sub = ix->opt_sub; // A/B selector for tools_ab.py (0 = shipped configuration)
         auto go = [&](auto kern, int threads) -> int {
             HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -417,23 +419,25 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             return MIPS_OK;
         };
         int rc2;
-        if (ix->ld == 1024) rc2 = go(mips::scan_kernel_v3<KL, 64, 1, 4, false, 0, true, 4, 2>, 256);
+        if (ix->ld == 1024) rc2 = go(mips::scan_kernel_v3<KL, 64, 1, 4, false, 0, 2, 4, 2>, 256);
         else if (ix->ld == 640) rc2 = go(mips::scan_kernel_v3<KL, 40, 1, 2, true>, 512);
         else if (ix->ld == 512) rc2 = go(mips::scan_kernel_v3<KL, 32, 1, 2, true>, 512);
         else if (ix->ld == 384) rc2 = go(mips::scan_kernel_v3<KL, 24, 1, 2, true>, 512);
         else if (ix->ld == 256) rc2 = go(mips::scan_kernel_v3<KL, 16, 1, 2, true>, 512);
         else if (ix->ld == 128) rc2 = go(mips::scan_kernel_v3<KL, 8, 1, 2, true>, 512);
-        else if (sub == 3) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, true, 8, 3, false>, 512);  // hardware s_barrier per block
-        else if (sub == 7) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, true, 8, 3, true, true>, 512);  // nt document DMA
-        else if (sub == 1) rc2 = go(mips::scan_kernel_v3<KL, 48, 2, 6, true, 0, false, 4, 3, true>, 256);  // 4 waves x 64 queries
+        else if (sub == 3) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, 2, 8, 3, false>, 512);  // hardware s_barrier per block
+        else if (sub == 7) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, 2, 8, 3, true, true>, 512);  // nt document DMA
+        else if (sub == 6) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, 1, 8, 3, true, false, 1>, 512);  // shared K'-th bests, re-read every block (the round's earlier default)
+        else if (sub == 15) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, 2, 8, 3, true, false, 1>, 512); // class maxima re-read every block
+        else if (sub == 1) rc2 = go(mips::scan_kernel_v3<KL, 48, 2, 6, true, 0, 0, 4, 3, true>, 256);  // 4 waves x 64 queries
         else if (sub == 10) rc2 = go(mips::scan_kernel_v3<6, 48, 1, 2, true>, 512);             // 6-entry lists
         else if (sub == 11) rc2 = go(mips::scan_kernel_v3<6, 48, 1, 3, true>, 512);             // 6-entry lists, prefetch depth 3
         else if (sub == 2) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, false>, 512);            // DMA issued in one burst
-        else if (sub == 4) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, false>, 512);   // no shared thresholds
+        else if (sub == 4) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, 0>, 512);       // no shared thresholds
         else if (sub == 5) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 3, true>, 512);             // prefetch depth 3
         else if (sub == 8) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 1>, 512);          // timing only: no epilogue
         else if (sub == 9) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 2>, 512);          // timing only: pre-test only
-        else if (nqt == 1) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, true, 8, 3, true, true>, 512);  // one query tile:
+        else if (nqt == 1) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, 2, 8, 3, true, true>, 512);  // one query tile:
         // every document block has a single reader, so its DMA is non-temporal (HBM-bound regime: 5.5 -> 5.9 TB/s)
         else rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true>, 512);
         if (rc2) return rc2;

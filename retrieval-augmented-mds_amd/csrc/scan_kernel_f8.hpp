@@ -86,15 +86,21 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_f8(ScanArgsF8 pa) {
         li[i] = IDX_NONE;
     }
 
-    // shared per-query thresholds (see scan_kernel_v3.hpp)
+    // shared per-query thresholds: class maxima, 8 words per query, sparse re-read (scan_kernel_v3.hpp, TMODE 2)
+    constexpr int PUB = KL <= 8 ? 1 : KL / 8; // a list publishes its PUB-th best: 8 classes x PUB >= K' documents
+    static_assert(8 * PUB >= KL, "the class words must prove at least K' documents");
     constexpr unsigned THR_AREA = STAGES * STAGE_BYTES;
-    const unsigned thr_addr = THR_AREA + wave * 256 + lane * 4;
-    *reinterpret_cast<unsigned*>(smem + thr_addr) = 0u;
+    constexpr unsigned THR_WAVE = 1024u;
+    constexpr unsigned DUMP_AREA = THR_AREA + WAVES * THR_WAVE;
+    static_assert(THR_AREA % 1024 == 0, "the wave areas are recovered from thr_addr by masking");
+    const unsigned thr_addr = THR_AREA + wave * THR_WAVE + lane * 16;
+    *reinterpret_cast<uint4*>(smem + thr_addr) = make_uint4(0u, 0u, 0u, 0u);
     const __amdgpu_buffer_rsrc_t thr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(reinterpret_cast<unsigned char*>(p.gthr) + (int64_t)qt * (WAVES * 256) - (int64_t)THR_AREA), 0,
-        (int)(THR_AREA + WAVES * 256), 0x00020000);
-    auto refresh_thresholds = [&]() {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rsrc, (lds_void*)(smem + THR_AREA + wave * 256), 4, thr_addr, 0, 0, 16);
+        (void*)(reinterpret_cast<unsigned char*>(p.gthr) + (int64_t)qt * (WAVES * THR_WAVE) - (int64_t)THR_AREA), 0,
+        (int)(THR_AREA + WAVES * THR_WAVE), 0x00020000);
+    auto refresh_thresholds = [&](bool real) { // !real: out-of-range dummy into the dump area (keeps vmcnt uniform)
+        lds_void* dst = (lds_void*)(smem + (real ? THR_AREA + wave * THR_WAVE : DUMP_AREA));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rsrc, dst, 16, real ? thr_addr : (thr_addr | 0x40000000u), 0, 0, 16);
     };
 
     // ---- LDS-DMA map: piece pc = slab * 4 + rg: rows 8 rg .. 8 rg + 7 of the 128-byte slab `slab`
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_f8(ScanArgsF8 pa) {
     const int rd_swz = (l31 >> 1) & 7;
 
     // split barrier on an LDS arrival counter (see scan_kernel_v3.hpp)
-    const unsigned cnt_lds = (unsigned)(size_t)(lds_void*)(smem + STAGES * STAGE_BYTES + WAVES * 256);
+    const unsigned cnt_lds = (unsigned)(size_t)(lds_void*)(smem + DUMP_AREA + 1024);
     unsigned arrivals_needed = 0;
     constexpr int PER_BLOCK = PPW + 1;
     auto arrive = [&]() {
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_f8(ScanArgsF8 pa) {
         }
     };
 
-    auto block = [&](int blk, int stage, const unsigned char* pbase, int pstage) {
+    auto block = [&](bool refresh, int blk, int stage, const unsigned char* pbase, int pstage) {
         const unsigned char* sa = smem + stage * STAGE_BYTES + rd_row;
         auto lds_frag = [&](int s) {
             // k-step s = 64 bytes = chunks 4 (s & 1) .. + 3 of slab s >> 1; this lane half takes two of them
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_f8(ScanArgsF8 pa) {
         v8i32 ar[AD];
 #pragma unroll
         for (int s = 0; s < AD; ++s) ar[s] = lds_frag(s);
-        refresh_thresholds(); // first VMEM op of the block
+        refresh_thresholds(refresh); // first VMEM op of the block
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -167,21 +173,29 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_f8(ScanArgsF8 pa) {
             __builtin_amdgcn_sched_barrier(0);
         }
         arrive(); // chain done, share of the next block landed; the epilogue below runs un-synchronised
-        const int base = blk * V3_DB + (int)((thr_addr >> 5) & 4u);
+        const int base = blk * V3_DB + (int)((thr_addr >> 7) & 4u);
         if ((int64_t)(blk + 1) * V3_DB > p.ntotal) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if ((int64_t)(base + (r & 3) + 8 * (r >> 2)) >= p.ntotal) acc[r] = -INFINITY;
         }
-        {
-            const unsigned key = *reinterpret_cast<const unsigned*>(smem + thr_addr);
+        if (refresh) { // minimum of the query's 8 class words (inline asm: see scan_kernel_v3.hpp)
+            const unsigned qwords = (unsigned)(size_t)(lds_void*)smem + (thr_addr & ~0x3FFu) + ((thr_addr & 0x1F0u) << 1);
+            u32x4 c0 = {0u, 0u, 0u, 0u}, c1 = {0u, 0u, 0u, 0u};
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(c0), "=&v"(c1)
+                         : "v"(qwords)
+                         : "memory");
+#endif
+            const unsigned key = min(min(min(c0[0], c0[1]), min(c0[2], c0[3])), min(min(c1[0], c1[1]), min(c1[2], c1[3])));
             thr = fmaxf(thr, key > 1u ? thr_decode(key - 1u) : -INFINITY);
         }
         float mx = acc[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
         if (__ballot(mx > thr) != 0ull) {
-            const float thr_in = thr;
+            const float mark = ls[PUB - 1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float s = acc[r];
@@ -190,7 +204,10 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_f8(ScanArgsF8 pa) {
                     thr = fmaxf(thr, ls[KL - 1]);
                 }
             }
-            if (ls[KL - 1] > thr_in) publish_umax(thr_encode(ls[KL - 1]), thr_addr, thr_rsrc);
+            if (ls[PUB - 1] > mark) { // this list vouches for more: raise its class word
+                const unsigned cls = (2u * (unsigned)split + ((thr_addr >> 9) & 1u)) & 7u;
+                publish_umax(thr_encode(ls[PUB - 1]), (thr_addr & ~0x3FFu) + ((thr_addr & 0x1F0u) << 1) + 4u * cls, thr_rsrc);
+            }
         }
     };
 
@@ -201,18 +218,18 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_f8(ScanArgsF8 pa) {
     if (nb > 0) {
 #pragma unroll
         for (int a = 0; a < AHEAD; ++a) { // same operation sequence as AHEAD steady-state blocks (vmcnt arithmetic)
-            refresh_thresholds();
+            refresh_thresholds(true);
             issue(a < nb ? first + a * blk_bytes : last, a);
         }
     }
     const unsigned char* pbase = nb > AHEAD ? first + AHEAD * blk_bytes : last;
     int stage = 0, pstage = AHEAD;
-    if (tid == 0) *reinterpret_cast<unsigned*>(smem + STAGES * STAGE_BYTES + WAVES * 256) = 0u;
+    if (tid == 0) *reinterpret_cast<unsigned*>(smem + DUMP_AREA + 1024) = 0u;
     __syncthreads(); // the one real barrier: arrival counter initialised
     if (nb > 0) arrive();
     for (int i = 0; i < nb; ++i) {
         wait_all();
-        block(b0 + i, stage, pbase, pstage);
+        block(i < 8 || (i & 7) == 0, b0 + i, stage, pbase, pstage); // refresh schedule: scan_kernel_v3.hpp
         if (i + AHEAD + 1 < nb) pbase += blk_bytes;
         stage = stage == STAGES - 1 ? 0 : stage + 1;
         pstage = pstage == STAGES - 1 ? 0 : pstage + 1;

@@ -64,12 +64,20 @@ __device__ __forceinline__ void publish_umax(unsigned key, unsigned voff, __amdg
 }
 
 typedef __attribute__((address_space(3))) void lds_void;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) void gbl_void;
 
-template <int KL, int KS16, int NQB, int AD, bool DMA_SPREAD, int TIMING_MODE = 0, bool GLOBAL_THR = true,
-          int WAVES = 8 / NQB, int STAGES = 3, bool SPLIT_BAR = true, bool NT_DOCS = false>
+// GLOBAL_THR: how the lists of one query (in different workgroups) share an insert bound --
+//   0 none, 1 every list publishes its K'-th best (one word per lane), 2 every list publishes its BEST into
+//   one of 8 class words of its query and the bound is the minimum of the 8 (see "shared thresholds" below).
+template <int KL, int KS16, int NQB, int AD, bool DMA_SPREAD, int TIMING_MODE = 0, int GLOBAL_THR = 2,
+          int WAVES = 8 / NQB, int STAGES = 3, bool SPLIT_BAR = true, bool NT_DOCS = false, int THR_PERIOD = 8>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs p) {
     constexpr int V3_TN = WAVES * NQB * 32;
+    constexpr int TMODE = NQB == 1 ? GLOBAL_THR : 0;
+    // TMODE 2 publishes a list's PUB-th best: 8 classes x PUB documents prove 8 PUB >= K' documents above the bound
+    constexpr int PUB = KL <= 8 ? 1 : KL / 8;
+    static_assert(8 * PUB >= KL && PUB <= KL, "the class words must prove at least K' documents");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int STAGE_BYTES = V3_DB * KS16 * 32; // 32 rows x (KS16 * 16) k x 2 B
     constexpr int PIECES = KS16;                   // 1 KiB pieces per block
@@ -129,28 +137,37 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
         }
     }
 
-    // ---- shared per-query thresholds.  All lists of a query (16+ splits x 2 lane halves, in different
-    // workgroups) publish their K'-th best score with an order-preserving atomicMax; every wave re-reads
-    // the 32 values of its queries once per block through one extra 256-byte LDS-DMA.  A document can
-    // only belong to the query's global top-K' if its score is >= every published value g (each g is
-    // some list's K'-th best, hence <= the global K'-th best), so the insert test becomes
+    // ---- shared per-query thresholds.  The lists of one query live in different workgroups (16+ splits x 2
+    // lane halves); left alone, each warms up on its own: ~K' ln(n / K') inserts per LIST.  They share a
+    // bound through p.gthr instead (order-preserving keys, atomic umax, re-read once per block by LDS-DMA).
+    // Any value g such that at least K' distinct documents of the query score >= g is a valid bound -- a
+    // document below g cannot be among the query's K' best -- and the insert test becomes
     //     s > max(own K'-th, nextbelow(g))      i.e.  s > own  and  s >= g
-    // -- ties with g are kept, the strict rule applies to the own list only, and a stale g (L1, DMA in
-    // flight) is merely a weaker bound.  This removes the per-list warm-up: ~K' ln(N/K') inserts per
-    // QUERY instead of per list.
-    // Layout of p.gthr: [query tile][wave][lane] (one slot per lane: lanes l and l + 32 of a query keep
-    // separate slots and exchange by shuffle, the same lane of OTHER splits shares the slot), so a wave's
-    // 64 slots are contiguous: one buffer_load_dword ... lds refreshes them.  thr_addr is this lane's
-    // slot in the LDS threshold area and, with the descriptor base shifted by the area offset, also the
-    // DMA's voffset -- one persistent VGPR for both.
+    // (ties with g are kept, the strict rule applies to the own list only; a stale g is merely weaker).
+    //   TMODE 1: g = some list's K'-th best.  One word per lane ([query tile][wave][lane]; the same lane of
+    //            other splits shares it), 256 B per wave.
+    //   TMODE 2: every list belongs to one of 8 classes, (2 split + lane half) & 7, and publishes its BEST
+    //            score (K' = 8; its K'/8-th best for longer lists) into the class word of its query; lists
+    //            hold disjoint documents, so the 8 class words vouch for 8 (K') distinct documents and g =
+    //            their minimum.  A list's best over the
+    //            documents of ALL lists of a class converges like the true top of the scan rather than like
+    //            one list's K'-th: the bound is useful after one insert per class instead of K' per list
+    //            (measured: 2^20 rows, Q = 256 -> 256 splits of 128 blocks: 0.575 ms with TMODE 1, of which
+    //            0.22 ms was this warm-up).  [query tile][wave][query][8 words], 1 KiB per wave = one
+    //            buffer_load_dwordx4 ... lds per block.
+    // thr_addr is this lane's chunk of the wave's LDS threshold area and, with the descriptor base shifted
+    // by the area offset, also the DMA's voffset -- one persistent VGPR for both.
     constexpr unsigned THR_AREA = STAGES * STAGE_BYTES;
-    const unsigned thr_addr = THR_AREA + wave * 256 + lane * 4;
+    constexpr unsigned THR_WAVE = TMODE == 2 ? 1024u : 256u;
+    static_assert(THR_AREA % 1024 == 0, "the wave areas are recovered from thr_addr by masking");
+    const unsigned thr_addr = THR_AREA + wave * THR_WAVE + lane * (TMODE == 2 ? 16 : 4);
     __amdgpu_buffer_rsrc_t thr_rsrc;
-    if (GLOBAL_THR) {
-        *reinterpret_cast<unsigned*>(smem + thr_addr) = 0u;
+    if (TMODE) {
+        if (TMODE == 2) *reinterpret_cast<uint4*>(smem + thr_addr) = make_uint4(0u, 0u, 0u, 0u);
+        else *reinterpret_cast<unsigned*>(smem + thr_addr) = 0u;
         thr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(reinterpret_cast<unsigned char*>(p.gthr) + (int64_t)qt * (WAVES * 256) - (int64_t)THR_AREA), 0,
-            (int)(THR_AREA + WAVES * 256), 0x00020000);
+            (void*)(reinterpret_cast<unsigned char*>(p.gthr) + (int64_t)qt * (WAVES * THR_WAVE) - (int64_t)THR_AREA), 0,
+            (int)(THR_AREA + WAVES * THR_WAVE), 0x00020000);
     }
 
     // ---- LDS-DMA map: piece pc = slab * 4 + rg covers rows 8 rg .. 8 rg + 7 of 64-k slab `slab`;
@@ -184,9 +201,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
     const int rd_row = l31 * 128;
     const int rd_swz = (l31 >> 1) & 7;
 
-    // one 256-byte LDS-DMA (sc1: served by L2, not by this CU's L1) re-reads the wave's 64 threshold slots
-    auto refresh_thresholds = [&]() {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rsrc, (lds_void*)(smem + THR_AREA + wave * 256), 4, thr_addr, 0, 0, 16);
+    // One LDS-DMA (sc1: served by L2, not by this CU's L1) re-reads the wave's threshold words.  `real` =
+    // false issues the same instruction with an out-of-range offset into a dump area: no memory access (the
+    // range check answers with zeros), but still one operation in the wave's vmcnt sequence, which keeps the
+    // counted waits uniform while the expensive re-read happens only every few blocks (schedule: main loop).
+    constexpr unsigned DUMP_AREA = THR_AREA + WAVES * THR_WAVE; // 1 KiB shared by all waves, never read
+    auto refresh_thresholds = [&](bool real) {
+        lds_void* dst = (lds_void*)(smem + (real ? THR_AREA + wave * THR_WAVE : DUMP_AREA));
+        const unsigned voff = real ? thr_addr : (thr_addr | 0x40000000u);
+        if (TMODE == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rsrc, dst, 16, voff, 0, 0, 16);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rsrc, dst, 4, voff, 0, 0, 16);
     };
 
     // ---- split barrier (SPLIT_BAR): gfx950's s_barrier is arrive-and-wait in one instruction, so one wave
@@ -198,10 +222,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
     // (WAR).  The spin is bounded; giving up sets p.err (results are then invalid, the kernel still ends).
     // The counter traffic is inline asm: for a volatile / atomic LDS access hipcc first drains vmcnt(0) (it
     // cannot prove the word does not alias an in-flight LDS-DMA destination), which would stall the ring.
-    unsigned* arrive_cnt = reinterpret_cast<unsigned*>(smem + STAGES * STAGE_BYTES + WAVES * 256);
+    unsigned* arrive_cnt = reinterpret_cast<unsigned*>(smem + DUMP_AREA + 1024);
     const unsigned cnt_lds = (unsigned)(size_t)(lds_void*)arrive_cnt; // 32-bit LDS byte address
     unsigned arrivals_needed = 0;
-    constexpr int PER_BLOCK_OPS = PPW + ((GLOBAL_THR && NQB == 1) ? 1 : 0);
+    // VMEM operations of one block, in issue order: the threshold refresh (real or dummy, see below), then its
+    // PPW DMA pieces (of block i + STAGES - 1): the same count every block, so that after chain i the operations
+    // younger than this wave's share of block i + 1 are exactly (STAGES - 2) blocks' worth.
+    constexpr int PER_BLOCK_OPS = PPW + (TMODE ? 1 : 0);
     auto arrive = [&]() {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_BLOCK_OPS) : "memory");
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -227,7 +254,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
     // scores block `blk` (ring stage `stage`); when pblk >= 0 the DMA pieces of block pblk are issued
     // one at a time between the MFMAs (spread over the chain: the partner wave keeps the matrix pipe busy
     // during an issue, which right after the barrier it could not, both waves being there together)
-    auto block = [&](int blk, int stage, const unsigned char* pbase, int pstage) {
+    // `refresh`: does this block re-read the shared threshold words (and apply them in its epilogue)?
+    auto block = [&](bool refresh, int blk, int stage, const unsigned char* pbase, int pstage) {
         const unsigned char* sa = smem + stage * STAGE_BYTES + rd_row;
         auto lds_frag = [&](int s) {
             return *reinterpret_cast<const bf16x8*>(sa + (s >> 2) * 4096 + (((2 * (s & 3) + h) ^ rd_swz) << 4));
@@ -243,7 +271,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
         bf16x8 ar[AD];
 #pragma unroll
         for (int s = 0; s < AD; ++s) ar[s] = lds_frag(s);
-        if (GLOBAL_THR && NQB == 1) refresh_thresholds(); // first VMEM op of the block
+        if (TMODE) refresh_thresholds(refresh); // first VMEM op of the block
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KS16; ++s) {
@@ -260,7 +288,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
             for (int n = 0; n < NQB; ++n) keep_alive(acc[n]);
             return;
         }
-        const int base = blk * V3_DB + (int)((thr_addr >> 5) & 4u); // + 4 * (lane >> 5), from the lane * 4 bits
+        // + 4 * (lane >> 5), from the lane bits of thr_addr
+        const int base = blk * V3_DB + (int)((thr_addr >> (TMODE == 2 ? 7 : 5)) & 4u);
         if ((int64_t)(blk + 1) * V3_DB > p.ntotal) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -269,8 +298,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
                     for (int n = 0; n < NQB; ++n) acc[n][r] = -INFINITY;
                 }
         }
-        if (GLOBAL_THR && NQB == 1) {
-            const unsigned key = *reinterpret_cast<const unsigned*>(smem + thr_addr); // an earlier block's DMA (or 0)
+        // the words an earlier block's DMA brought (or 0)
+        if (TMODE == 1 && refresh) {
+            const unsigned key = *reinterpret_cast<const unsigned*>(smem + thr_addr);
+            thr[0] = fmaxf(thr[0], key > 1u ? thr_decode(key - 1u) : -INFINITY);
+        } else if (TMODE == 2 && refresh) {
+            // wave area + 32 B * (lane & 31).  Read in inline asm: for an ordinary load of a DMA destination
+            // hipcc first drains vmcnt(0), i.e. the whole document ring, once per block.
+            const unsigned qwords = (unsigned)(size_t)(lds_void*)smem + (thr_addr & ~0x3FFu) + ((thr_addr & 0x1F0u) << 1);
+            u32x4 c0 = {0u, 0u, 0u, 0u}, c1 = {0u, 0u, 0u, 0u};
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(c0), "=&v"(c1)
+                         : "v"(qwords)
+                         : "memory");
+#endif
+            const unsigned key = min(min(min(c0[0], c0[1]), min(c0[2], c0[3])), min(min(c1[0], c1[1]), min(c1[2], c1[3])));
             thr[0] = fmaxf(thr[0], key > 1u ? thr_decode(key - 1u) : -INFINITY);
         }
 #pragma unroll
@@ -283,7 +326,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
                 continue;
             }
             if (__ballot(mx > thr[n]) != 0ull) {
-                const float thr_in = thr[n];
+                const float mark = TMODE == 2 ? ls[n][PUB - 1] : thr[n]; // what a publication must beat
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float s = acc[n][r];
@@ -292,8 +335,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
                         thr[n] = fmaxf(thr[n], ls[n][KL - 1]);
                     }
                 }
-                if (GLOBAL_THR && NQB == 1 && ls[n][KL - 1] > thr_in) // own K'-th now beats every bound seen: publish
+                if (TMODE == 1 && ls[n][KL - 1] > mark) // own K'-th now beats every bound seen: publish
                     publish_umax(thr_encode(ls[n][KL - 1]), thr_addr, thr_rsrc);
+                if (TMODE == 2 && ls[n][PUB - 1] > mark) { // this list vouches for more: raise its class word
+                    const unsigned cls = (2u * (unsigned)split + ((thr_addr >> 9) & 1u)) & 7u;
+                    publish_umax(thr_encode(ls[n][PUB - 1]), (thr_addr & ~0x3FFu) + ((thr_addr & 0x1F0u) << 1) + 4u * cls, thr_rsrc);
+                }
             }
         }
     };
@@ -312,7 +359,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
         // the first block: a cold-start race caught by test_mips_facade_end_to_end.)
 #pragma unroll
         for (int a = 0; a < AHEAD; ++a) {
-            if (GLOBAL_THR && NQB == 1) refresh_thresholds();
+            if (TMODE) refresh_thresholds(true);
             issue(a < nb ? first + a * blk_bytes : last, a);
         }
     }
@@ -320,11 +367,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
     int stage = 0, pstage = AHEAD;
     // VMEM operations a wave issues per block: its DMA pieces and the threshold refresh; at the top of
     // block i everything older than the (STAGES - 2) youngest blocks' worth must have landed
-    constexpr int PER_BLOCK = PPW + ((GLOBAL_THR && NQB == 1) ? 1 : 0);
+    constexpr int PER_BLOCK = PPW + (TMODE ? 1 : 0);
     if (SPLIT_BAR) {
         if (tid == 0) *arrive_cnt = 0u;
         __syncthreads(); // the one real barrier: counter initialised (its vmcnt(0) also settles the prologue's loads)
-        if (nb > 0) arrive();         // prologue arrival: this wave's share of block 0 has landed
+        if (nb > 0) arrive();   // prologue arrival: this wave's share of block 0 has landed
     }
     for (int i = 0; i < nb; ++i) {
         if (SPLIT_BAR) {
@@ -334,7 +381,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
             __builtin_amdgcn_s_barrier(); // all shares of block i landed; everyone is done with block i-1
         }
         if (!DMA_SPREAD) issue(pbase, pstage);
-        block(b0 + i, stage, pbase, pstage);
+        // Threshold refresh schedule: every block while the lists warm up, every 8th afterwards.  All the
+        // workgroups of a query tile re-read the same few cache lines, which the publications keep evicting
+        // from L2 (atomics drop the line): refreshed every block by 256 workgroups those lines saturate, and
+        // the refresh, completing in order with the document DMA, stalls the ring (2^20 rows, Q = 256: sharing
+        // was SLOWER than no sharing, 0.477 vs 0.447 ms).
+        block(THR_PERIOD == 1 || i < 8 || (i % THR_PERIOD) == 0, b0 + i, stage, pbase, pstage);
         if (i + AHEAD + 1 < nb) pbase += blk_bytes; // stops at the last block
         stage = stage == STAGES - 1 ? 0 : stage + 1;
         pstage = pstage == STAGES - 1 ? 0 : pstage + 1;

@@ -13,8 +13,9 @@ ap.add_argument("--dim", type=int, default=768)
 ap.add_argument("--k", type=int, default=5)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--dtype", default="bf16")
 a = ap.parse_args()
-ix = ram.MipsIndex(a.dim)
+ix = ram.MipsIndex(a.dim, dtype=a.dtype)
 ix.add_synthetic(a.rows, 0, ram.SEED_DOCS, ram.SYNTH_GAUSS)
 q = ram.synth_fill(a.queries, a.dim, 0, ram.SEED_QUERIES, ram.SYNTH_GAUSS)
 ref = None
