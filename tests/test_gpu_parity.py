@@ -769,8 +769,9 @@ def test_np_search_is_inner_product_even_on_an_l2_index(tmp_path):
 
 def test_experimental_scan_variants_are_bit_identical():
     """Launch-tuning knobs never change results: the 16x16x32 kernel (variant 4), the 6-entry-list forms
-    (sub 10 / 11), the s_barrier form (sub 3), the generic kernel (variant 1) and other split counts all
-    return the shipped configuration's bits."""
+    (sub 10 / 11), the s_barrier form (sub 3), the other insert-bound schemes (sub 4 none, sub 6 shared K'-th
+    bests, sub 15 class maxima re-read every block), the generic kernel (variant 1) and other split counts
+    all return the shipped configuration's bits."""
     n, nq, d, k = 150001, 700, 768, 5
     ix = ram.MipsIndex(d)
     ix.add_synthetic(n, row0=0, seed=171, kind=synth.KIND_GAUSS)
@@ -780,6 +781,7 @@ def test_experimental_scan_variants_are_bit_identical():
     es, ei = orc.search_exact(q.float().cpu().numpy()[:64], x, k)
     assert np.array_equal(ref_i[:64].cpu().numpy(), ei) and np.array_equal(ref_s[:64].cpu().numpy(), es)
     for params in ({"variant": 4}, {"variant": 3, "sub": 10}, {"variant": 3, "sub": 11}, {"variant": 3, "sub": 3},
+                   {"variant": 3, "sub": 4}, {"variant": 3, "sub": 6}, {"variant": 3, "sub": 15}, {"variant": 3, "sub": 7},
                    {"variant": 1}, {"variant": 3, "nsplit": 40}, {"variant": 3, "qgroups": 2}, {"variant": 4, "nsplit": 8}):
         for name in ("variant", "sub", "nsplit", "qgroups"):
             ix.set_param(name, params.get(name, 0))
