@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64) void rescore_rank_kernel(MergeArgs p, const int
     const int lane = threadIdx.x;
     const int64_t q = (int64_t)blockIdx.x * QPW + lane / KL;
     const int slot = lane % KL;
-    const bool inq = q < nq;
+    const bool inq = q < nq && lane < QPW * KL; // K' = 10: lanes 60..63 belong to no query
     const int ci = inq ? cand[(size_t)q * KL + slot] : IDX_NONE;
     const bool valid = ci != IDX_NONE;
     double dot = 0.0, qq = 0.0;

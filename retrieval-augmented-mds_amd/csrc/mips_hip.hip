@@ -271,17 +271,19 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     if (variant != 1 && variant != 3) variant = 3;
     const bool v3_dim = (ix->ld % 128 == 0 && ix->ld <= 768) || ix->ld == 1024;
     const bool v3_long = ix->ld == 256 || ix->ld == 512 || ix->ld == 768; // pitches with K' = 16 / 32 instances
+    constexpr bool kl_short = KL <= 10; // K' = 8 / 10 lists fit the 8-wave (two per SIMD) configuration
     const bool f8 = ix->esize == 1; // e4m3 index: scan_kernel_f8 only (row lengths 256..1024, K' <= 16)
     const bool f32x = ix->plane > 0; // fp32-exact mode: generic kernel over the [hi | lo] planes, three k segments
     if (f8) {
         if (ix->ld % 256 != 0 || ix->ld > 1024 || KL > 16) return fail(MIPS_E_UNSUPPORTED, "fp8 index: d must pad to 256/512/768/1024 and k <= 13");
         variant = 3;
-    } else if (f32x || !v3_dim || (KL != 8 && !v3_long)) {
+    } else if (f32x || !v3_dim || (!kl_short && !v3_long)) {
         variant = 1; // no query-stationary configuration: generic tiles
     }
-    // K' = 8 at d <= 768: 8 waves, two per SIMD (256 registers each).  Longer lists (k > 5) or d = 1024 do
-    // not fit next to the fragments there: 4 waves, one per SIMD, 512 registers, 128 queries per workgroup.
-    const int v3_waves = (!f8 && (ix->ld == 1024 || KL != 8)) ? 4 : 8;
+    // K' = 8 / 10 (k <= 7) at d <= 768: 8 waves, two per SIMD (256 registers each, no spill up to K' = 10).
+    // Longer lists or d = 1024 do not fit next to the fragments there: 4 waves, one per SIMD, 512 registers,
+    // 128 queries per workgroup.
+    const int v3_waves = (!f8 && (ix->ld == 1024 || !kl_short)) ? 4 : 8;
     const int tm = variant == 1 ? mips::TM : mips::V3_DB;             // documents per scheduling unit ("tile")
     const int tn = variant == 1 ? mips::TN : v3_waves * 32;           // queries per workgroup
     const int lists = want_v4 ? 4 : 2;                                // running lists per (query, split)
@@ -395,7 +397,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
                                     mips::SCAN_LDS_BYTES));
         HIP_TRY(hipEventRecord(ix->ev0[slot], st));
         mips::scan_kernel<KL><<<grid, mips::SCAN_THREADS, mips::SCAN_LDS_BYTES, st>>>(a);
-    } else if constexpr (KL != 8) {
+    } else if constexpr (!kl_short) {
         // 4-wave configuration, 3-stage ring (d <= 768: 3 x 48 KiB)
         const int lds = 3 * mips::V3_DB * ix->ld * 2 + 4 * 1024 + 1024 + 16;
         auto go4 = [&](auto kern) -> int {
@@ -411,7 +413,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         if (rc2) return rc2;
     } else {
         const int lds = (v3_waves == 4 ? 2 : 3) * mips::V3_DB * ix->ld * 2 + v3_waves * 1024 + 1024 + 16; // ring + threshold words + dump area + arrival counter
-        const int sub = ix->opt_sub; // A/B selector for tools_ab.py (0 = shipped configuration)
+        const int sub = KL == 8 ? ix->opt_sub : 0; // A/B selector for tools/ab.py (0 = shipped configuration)
         auto go = [&](auto kern, int threads) -> int {
             HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             HIP_TRY(hipEventRecord(ix->ev0[slot], st));
@@ -730,8 +732,11 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
         rc = convert_into(ix, q, nq, q_dtype, (flags & MIPS_Q_DEVICE) ? 1 : 0, qb, st, qkeep);
         if (rc) return rc;
         if (nq_pad > nq) HIP_TRY(hipMemsetAsync(qb + (size_t)nq * row_bytes, 0, (size_t)(nq_pad - nq) * row_bytes, st));
+        // K' = list length of the scan >= k + 3: the MFMA scores only SELECT candidates
         if (k <= 5)
             rc = launch_search<8>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st);
+        else if (k <= 7) // k + 1 = 6 is what Mips.search fetches for top_k = 5 with ignore_indexes (mips.py:388-398)
+            rc = launch_search<10>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st);
         else if (k <= 13)
             rc = launch_search<16>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st);
         else

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_f8(ScanArgsF8 pa) {
     }
 
     // shared per-query thresholds: class maxima, 8 words per query, sparse re-read (scan_kernel_v3.hpp, TMODE 2)
-    constexpr int PUB = KL <= 8 ? 1 : KL / 8; // a list publishes its PUB-th best: 8 classes x PUB >= K' documents
+    constexpr int PUB = (KL + 7) / 8; // a list publishes its PUB-th best: 8 classes x PUB >= K' documents
     static_assert(8 * PUB >= KL, "the class words must prove at least K' documents");
     constexpr unsigned THR_AREA = STAGES * STAGE_BYTES;
     constexpr unsigned THR_WAVE = 1024u;

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
     constexpr int V3_TN = WAVES * NQB * 32;
     constexpr int TMODE = NQB == 1 ? GLOBAL_THR : 0;
     // TMODE 2 publishes a list's PUB-th best: 8 classes x PUB documents prove 8 PUB >= K' documents above the bound
-    constexpr int PUB = KL <= 8 ? 1 : KL / 8;
+    constexpr int PUB = (KL + 7) / 8;
     static_assert(8 * PUB >= KL && PUB <= KL, "the class words must prove at least K' documents");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int STAGE_BYTES = V3_DB * KS16 * 32; // 32 rows x (KS16 * 16) k x 2 B

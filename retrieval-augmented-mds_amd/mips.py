@@ -26,7 +26,7 @@ from __future__ import annotations
 import json
 import pickle
 import shutil
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from pathlib import Path
 from random import random
 

@@ -105,14 +105,17 @@ def test_cfg1_matches_reference_golden(golden_dir):
                                        (20000, 130, 769, 16), (131, 3, 64, 13), (128, 128, 64, 6),
                                        # query-stationary kernel configurations: d = 1024 (4 waves), 512, 256, padded 500
                                        (70001, 300, 1024, 5), (33, 1, 1024, 3), (50000, 513, 512, 5),
-                                       (9000, 40, 256, 4), (12345, 70, 500, 5)])
+                                       (9000, 40, 256, 4), (12345, 70, 500, 5),
+                                       # K' = 10 tier (k = 6, 7; k + 1 = 6 is Mips.search's fetch for top_k = 5 with ignore_indexes)
+                                       (100003, 300, 768, 6), (40000, 257, 768, 7), (20011, 64, 1024, 6), (9000, 33, 512, 7),
+                                       (3001, 9, 100, 6)])
 def test_ragged_shapes_gauss(n, nq, d, k):
     x = synth.generate(21, 0, n, d, synth.KIND_GAUSS)
     q = synth.generate(22, 0, nq, d, synth.KIND_GAUSS)
     _check(_index(x), q, x, k)
 
 
-@pytest.mark.parametrize("k", [1, 5, 6, 13, 14, 29])
+@pytest.mark.parametrize("k", [1, 5, 6, 7, 8, 13, 14, 29])
 def test_k_variants_lattice(k):
     x = synth.generate(31, 0, 5000, 128, synth.KIND_LATTICE)
     q = synth.generate(32, 0, 33, 128, synth.KIND_LATTICE)
@@ -587,7 +590,7 @@ def test_fp8_quantizer_device_matches_host():
 
 
 @pytest.mark.parametrize("n,nq,d,k", [(5000, 40, 768, 5), (70001, 300, 768, 5), (4099, 129, 1024, 10), (3000, 7, 256, 1),
-                                       (9000, 70, 500, 13), (33, 2, 512, 5)])
+                                       (9000, 70, 500, 13), (33, 2, 512, 5), (30001, 260, 768, 6)])
 def test_fp8_index_parity(n, nq, d, k):
     """Index and queries quantised to e4m3; the oracle consumes the same quantised values."""
     for kind in (synth.KIND_LATTICE_FP8, synth.KIND_GAUSS):

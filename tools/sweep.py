@@ -1,7 +1,7 @@
 """Q sweep / size sweep on one GPU (GPU box): scan-kernel time and whole-call time per configuration."""
 import argparse, json, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 import retrieval_augmented_mds_amd as ram
 
 ap = argparse.ArgumentParser()
