@@ -1,0 +1,144 @@
+// What does v_mfma_f32_32x32x16_bf16 sustain on THIS chip, under its power management, when nothing else is
+// in the way?  A diagnostic, not part of the product: bare MFMA loops with the scan kernel's occupancy
+// (8 waves per CU, two per SIMD, one accumulation chain per wave), run back to back for >= 2 s per case so
+// the clock settles.  Cases: operands all zero / random N(0,1) bf16 in registers / the A operand re-read
+// from LDS by one ds_read_b128 per MFMA (the scan kernel's inner loop without DMA, barrier or epilogue).
+// The scan kernel's TFLOP/s is to be read against the random-data rows, not against 2.5 PFLOP/s alone.
+//
+//   hipcc -O3 --offload-arch=gfx950 -o /tmp/mfma_ceiling tools/mfma_ceiling.hip && /tmp/mfma_ceiling
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CHECK(x)                                                                      \
+    do {                                                                              \
+        hipError_t e_ = (x);                                                          \
+        if (e_ != hipSuccess) {                                                       \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                   \
+            exit(1);                                                                  \
+        }                                                                             \
+    } while (0)
+
+constexpr int NFRAG = 16;   // distinct register-resident B fragments per wave (64 VGPRs)
+constexpr int MFMA_PER_IT = 48; // as one 32-document block at d = 768
+
+// MODE 0: A and B from registers; MODE 1: A re-read from LDS (conflict-free rows of 128 B) per MFMA
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void mfma_loop(const uint16_t* src, float* sink, int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[48 * 1024];
+    const int lane = threadIdx.x & 63;
+    bf16x8 b[NFRAG], a[2];
+    const uint16_t* base = src + ((size_t)blockIdx.x * 512 + threadIdx.x) * 8;
+#pragma unroll
+    for (int i = 0; i < NFRAG; ++i) b[i] = *reinterpret_cast<const bf16x8*>(base + (size_t)i * 512 * 8 * gridDim.x);
+    a[0] = b[3];
+    a[1] = b[7];
+    if (MODE == 1) {
+        for (int o = threadIdx.x * 16; o < 48 * 1024; o += 512 * 16)
+            *reinterpret_cast<bf16x8*>(lds + o) = *reinterpret_cast<const bf16x8*>(src + (o / 2) % 4096 + (size_t)blockIdx.x * 4096);
+        __syncthreads();
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int row = (lane & 31) * 128, h = lane >> 5, swz = ((lane & 31) >> 1) & 7;
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 1) {
+            bf16x8 ar[2];
+            auto frag = [&](int s) { return *reinterpret_cast<const bf16x8*>(lds + row + (s >> 2) * 4096 + (((2 * (s & 3) + h) ^ swz) << 4)); };
+            ar[0] = frag(0);
+            ar[1] = frag(1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < MFMA_PER_IT; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[s & 1], b[s % NFRAG], acc, 0, 0, 0);
+                if (s + 2 < MFMA_PER_IT) ar[s & 1] = frag(s + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < MFMA_PER_IT; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1], b[s % NFRAG], acc, 0, 0, 0);
+        }
+        // keep the chain bounded (random data would overflow fp32 after ~1e5 steps): fold it back cheaply
+        if ((it & 63) == 63) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= 1e-6f;
+        }
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += acc[r];
+    if (t == 12345.678f) sink[0] = t; // never true; keeps the chain alive
+}
+
+static uint64_t mix(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+template <int MODE>
+static void run(const char* name, const uint16_t* d_src, float* d_sink, int grid, double seconds) {
+    const int iters = 4096;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int w = 0; w < 3; ++w) mfma_loop<MODE><<<grid, 512>>>(d_src, d_sink, iters);
+    CHECK(hipDeviceSynchronize());
+    double best = 0, last = 0, total_ms = 0;
+    int launches = 0;
+    while (total_ms < seconds * 1e3) {
+        CHECK(hipEventRecord(e0));
+        for (int r = 0; r < 8; ++r) mfma_loop<MODE><<<grid, 512>>>(d_src, d_sink, iters);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        total_ms += ms;
+        launches += 8;
+        const double flops = 8.0 * grid * 8.0 * iters * MFMA_PER_IT * 32768.0;
+        last = flops / (ms * 1e-3) / 1e12;
+        if (last > best) best = last;
+    }
+    printf("{\"case\": \"%s\", \"tflops_last\": %.1f, \"tflops_best\": %.1f, \"launches\": %d, \"workgroups\": %d}\n", name, last, best, launches, grid);
+    fflush(stdout);
+}
+
+int main() {
+    int dev = 0;
+    CHECK(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, dev));
+    const int grid = prop.multiProcessorCount; // one 8-wave workgroup per CU, as the scan kernel
+    const size_t n = (size_t)NFRAG * grid * 512 * 8 + 4096 * (size_t)grid;
+    uint16_t* h = (uint16_t*)malloc(n * 2);
+    uint16_t *d_rand, *d_zero;
+    float* d_sink;
+    // N(0,1)-like bf16 (sum of 8 uniforms, as the bench data generator)
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t a = mix(i * 2), b = mix(i * 2 + 1);
+        int64_t s = 0;
+        for (int sh = 0; sh < 64; sh += 16) s += (int64_t)((a >> sh) & 0xFFFF) + (int64_t)((b >> sh) & 0xFFFF);
+        float f = (float)(s - 4 * 65535) * (1.0f / (65536.0f * 0.8165f));
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        h[i] = (uint16_t)((u + 0x7FFF + ((u >> 16) & 1)) >> 16);
+    }
+    CHECK(hipMalloc(&d_rand, n * 2));
+    CHECK(hipMalloc(&d_zero, n * 2));
+    CHECK(hipMalloc(&d_sink, 64));
+    CHECK(hipMemcpy(d_rand, h, n * 2, hipMemcpyHostToDevice));
+    CHECK(hipMemset(d_zero, 0, n * 2));
+    printf("{\"device\": \"%s\", \"compute_units\": %d}\n", prop.name, grid);
+    run<0>("registers, zeros", d_zero, d_sink, grid, 2.0);
+    run<0>("registers, random N(0,1) bf16", d_rand, d_sink, grid, 2.0);
+    run<1>("A from LDS (ds_read_b128 per MFMA), zeros", d_zero, d_sink, grid, 2.0);
+    run<1>("A from LDS (ds_read_b128 per MFMA), random N(0,1) bf16", d_rand, d_sink, grid, 2.0);
+    return 0;
+}
