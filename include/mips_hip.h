@@ -190,8 +190,9 @@ int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out
 
 /* Tuning knobs of the scan launch (0 = automatic): "nsplit" = number of index splits (rounded up
  * to a multiple of 8), "qgroups" = query-tile groups per XCD octet (1, 2, 4 or 8), "variant" = scan kernel (1 = 128x128
- * register-staged tiles, 3 = query-stationary LDS-DMA, used when d pads to 768).  Results never
- * depend on them; only speed does. */
+ * register-staged tiles, 3 = query-stationary on the 32x32x16 MFMA shape, 4 = query-stationary on the
+ * 16x16x32 shape (d padding to 768, k <= 5)), "sub" = A/B selector of experimental instances of variant 3
+ * (profiles/ experiment logs).  Results never depend on them; only speed does. */
 int mips_index_set_param(mips_index_t* index, const char* name, int64_t value);
 
 /* Timing hook used by bench.py: every mips_search records a HIP event pair around its fused scan

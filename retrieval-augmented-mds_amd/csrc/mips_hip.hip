@@ -113,7 +113,7 @@ struct mips_index {
     int opt_qgroups = 0;
     size_t err_off = 0; // word offset of the scan kernel's error flag inside gthr (0 = none this call)
     int opt_sub = 0;
-    int opt_variant = 0; // 1 = scan_kernel (128x128 tiles, register staged), 3 = scan_kernel_v3 (query-stationary, LDS-DMA)
+    int opt_variant = 0; // 0 = automatic, 1 = scan_kernel (128x128 tiles), 3 = scan_kernel_v3 (32x32x16), 4 = scan_kernel_v4 (16x16x32)
     hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
     int ev_count = 0; // pairs recorded since the last reset (saturates at kEvRing)
     int ev_next = 0;
@@ -267,7 +267,13 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // variant 3 (query-stationary, LDS-DMA): the whole K of a wave's 32 queries lives in its VGPRs, so it
     // exists for a few row lengths only: 256 / 512 / 768 (8 waves, 2 per SIMD) and 1024 (4 waves, 1 per SIMD)
     int variant = ix->opt_variant;
-    const bool want_v4 = variant == 4 && ix->ld == 768 && KL == 8 && ix->esize == 2 && ix->plane == 0; // 16x16x32 experiment
+    // scan_kernel_v4 (16x16x32 MFMA shape, 4 sub-lists of 6): d pads to 768, k <= 5, bf16 storage.  It is the default
+    // there when more than one query tile shares the document stream (the MFMA-bound regime, where the shape's
+    // higher clock pays: 4.54 vs 4.78 ms at BASELINE config 2); single-tile searches are HBM-bound and keep
+    // scan_kernel_v3's non-temporal document DMA.  "variant" = 3 / 4 forces one of the two.
+    const bool v4_shape = ix->ld == 768 && KL == 8 && ix->esize == 2 && ix->plane == 0;
+    const bool v4_forced = variant == 4 && v4_shape;
+    const bool v4_auto = variant == 0 && ix->opt_sub == 0 && v4_shape;
     if (variant != 1 && variant != 3) variant = 3;
     const bool v3_dim = (ix->ld % 128 == 0 && ix->ld <= 768) || ix->ld == 1024;
     const bool v3_long = ix->ld == 256 || ix->ld == 512 || ix->ld == 768; // pitches with K' = 16 / 32 instances
@@ -286,10 +292,11 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     const int v3_waves = (!f8 && (ix->ld == 1024 || !kl_short)) ? 4 : 8;
     const int tm = variant == 1 ? mips::TM : mips::V3_DB;             // documents per scheduling unit ("tile")
     const int tn = variant == 1 ? mips::TN : v3_waves * 32;           // queries per workgroup
-    const int lists = want_v4 ? 4 : 2;                                // running lists per (query, split)
     const int wg_target = variant == 1 ? 512 : 256;                   // resident workgroups on 256 CUs
     const int64_t nq_pad = round_up(nq, kQueryAlign);
     const int nqt = (int)((nq + tn - 1) / tn);
+    const bool want_v4 = v4_forced || (v4_auto && nqt > 1);
+    const int lists = want_v4 ? 4 : 2;                                // running lists per (query, split)
     const int ntiles = (int)((ix->ntotal + tm - 1) / tm);
     // Index splits (a multiple of 8: one XCD group each).  The grid nqt x nsplit should come in whole
     // "rounds" of wg_target resident workgroups: among the multiples of 8 up to 64 take the one whose last
@@ -367,10 +374,16 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     const int slot = ix->ev_next;
     if (want_v4) {
         if constexpr (KL == 8) {
-            const int lds = 3 * mips::V3_DB * ix->ld * 2 + 8 * 256 + 16;
-            HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel_v4<V4_KLL, 24, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            HIP_TRY(hipEventRecord(ix->ev0[slot], st));
-            mips::scan_kernel_v4<V4_KLL, 24, 2><<<grid, 512, lds, st>>>(a);
+            const int lds = 3 * mips::V3_DB * ix->ld * 2 + 8 * 1024 + 1024 + 16;
+            if (ix->opt_sub == 8) { // timing only: no epilogue
+                HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel_v4<V4_KLL, 24, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HIP_TRY(hipEventRecord(ix->ev0[slot], st));
+                mips::scan_kernel_v4<V4_KLL, 24, 2, 1><<<grid, 512, lds, st>>>(a);
+            } else {
+                HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel_v4<V4_KLL, 24, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HIP_TRY(hipEventRecord(ix->ev0[slot], st));
+                mips::scan_kernel_v4<V4_KLL, 24, 2><<<grid, 512, lds, st>>>(a);
+            }
         }
     } else if (f8) {
         if constexpr (KL <= 16) {

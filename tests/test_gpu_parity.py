@@ -783,7 +783,7 @@ def test_experimental_scan_variants_are_bit_identical():
     x = synth.generate(171, 0, n, d, synth.KIND_GAUSS)
     es, ei = orc.search_exact(q.float().cpu().numpy()[:64], x, k)
     assert np.array_equal(ref_i[:64].cpu().numpy(), ei) and np.array_equal(ref_s[:64].cpu().numpy(), es)
-    for params in ({"variant": 4}, {"variant": 3, "sub": 10}, {"variant": 3, "sub": 11}, {"variant": 3, "sub": 3},
+    for params in ({"variant": 4}, {"variant": 3}, {"variant": 3, "sub": 10}, {"variant": 3, "sub": 11}, {"variant": 3, "sub": 3},
                    {"variant": 3, "sub": 4}, {"variant": 3, "sub": 6}, {"variant": 3, "sub": 15}, {"variant": 3, "sub": 7},
                    {"variant": 1}, {"variant": 3, "nsplit": 40}, {"variant": 3, "qgroups": 2}, {"variant": 4, "nsplit": 8}):
         for name in ("variant", "sub", "nsplit", "qgroups"):

@@ -14,6 +14,7 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define CHECK(x)                                                                      \
     do {                                                                              \
@@ -76,6 +77,60 @@ __global__ __launch_bounds__(512, 2) void mfma_loop(const uint16_t* src, float* 
     if (t == 12345.678f) sink[0] = t; // never true; keeps the chain alive
 }
 
+// The 16x16x32 shape at the same bytes and flops per wave: per step ONE A fragment (16 documents x 32 k, from
+// registers or LDS) feeds two MFMAs (two 16-query column blocks), as scan_kernel_v4 does.  MODE as above.
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void mfma_loop16(const uint16_t* src, float* sink, int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[48 * 1024];
+    const int lane = threadIdx.x & 63;
+    bf16x8 b[NFRAG], a[2];
+    const uint16_t* base = src + ((size_t)blockIdx.x * 512 + threadIdx.x) * 8;
+#pragma unroll
+    for (int i = 0; i < NFRAG; ++i) b[i] = *reinterpret_cast<const bf16x8*>(base + (size_t)i * 512 * 8 * gridDim.x);
+    a[0] = b[3];
+    a[1] = b[7];
+    if (MODE == 1) {
+        for (int o = threadIdx.x * 16; o < 48 * 1024; o += 512 * 16)
+            *reinterpret_cast<bf16x8*>(lds + o) = *reinterpret_cast<const bf16x8*>(src + (o / 2) % 4096 + (size_t)blockIdx.x * 4096);
+        __syncthreads();
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int c = lane & 15, g = lane >> 4, swz = (c >> 1) & 7;
+    const int rd0 = c * 128 + ((g ^ swz) << 4);
+    for (int it = 0; it < iters; ++it) {
+        // 48 steps x 2 MFMAs of 16x16x32 = the flops of 48 MFMAs of 32x32x16 ... per HALF block; two halves
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (MODE == 1) {
+                bf16x8 ar[2];
+                auto frag = [&](int s) { return *reinterpret_cast<const bf16x8*>(lds + half * 2048 + (s >> 1) * 4096 + ((s & 1) ? (rd0 ^ 64) : rd0)); };
+                ar[0] = frag(0);
+                ar[1] = frag(1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 24; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[s & 1], b[(2 * s) % NFRAG], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[s & 1], b[(2 * s + 1) % NFRAG], acc1, 0, 0, 0);
+                    if (s + 2 < 24) ar[s & 1] = frag(s + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 24; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1], b[(2 * s) % NFRAG], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1], b[(2 * s + 1) % NFRAG], acc1, 0, 0, 0);
+                }
+            }
+        }
+        if ((it & 63) == 63) {
+            acc0 *= 1e-6f;
+            acc1 *= 1e-6f;
+        }
+    }
+    float t = acc0[0] + acc0[1] + acc0[2] + acc0[3] + acc1[0] + acc1[1] + acc1[2] + acc1[3];
+    if (t == 12345.678f) sink[0] = t;
+}
+
 static uint64_t mix(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -83,26 +138,26 @@ static uint64_t mix(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-template <int MODE>
-static void run(const char* name, const uint16_t* d_src, float* d_sink, int grid, double seconds) {
+typedef void (*kern_t)(const uint16_t*, float*, int);
+static void run(kern_t kern, double flops_per_wave_iter, const char* name, const uint16_t* d_src, float* d_sink, int grid, double seconds) {
     const int iters = 4096;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    for (int w = 0; w < 3; ++w) mfma_loop<MODE><<<grid, 512>>>(d_src, d_sink, iters);
+    for (int w = 0; w < 3; ++w) kern<<<grid, 512>>>(d_src, d_sink, iters);
     CHECK(hipDeviceSynchronize());
     double best = 0, last = 0, total_ms = 0;
     int launches = 0;
     while (total_ms < seconds * 1e3) {
         CHECK(hipEventRecord(e0));
-        for (int r = 0; r < 8; ++r) mfma_loop<MODE><<<grid, 512>>>(d_src, d_sink, iters);
+        for (int r = 0; r < 8; ++r) kern<<<grid, 512>>>(d_src, d_sink, iters);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms = 0;
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         total_ms += ms;
         launches += 8;
-        const double flops = 8.0 * grid * 8.0 * iters * MFMA_PER_IT * 32768.0;
+        const double flops = 8.0 * grid * 8.0 * iters * flops_per_wave_iter;
         last = flops / (ms * 1e-3) / 1e12;
         if (last > best) best = last;
     }
@@ -136,9 +191,14 @@ int main() {
     CHECK(hipMemcpy(d_rand, h, n * 2, hipMemcpyHostToDevice));
     CHECK(hipMemset(d_zero, 0, n * 2));
     printf("{\"device\": \"%s\", \"compute_units\": %d}\n", prop.name, grid);
-    run<0>("registers, zeros", d_zero, d_sink, grid, 2.0);
-    run<0>("registers, random N(0,1) bf16", d_rand, d_sink, grid, 2.0);
-    run<1>("A from LDS (ds_read_b128 per MFMA), zeros", d_zero, d_sink, grid, 2.0);
-    run<1>("A from LDS (ds_read_b128 per MFMA), random N(0,1) bf16", d_rand, d_sink, grid, 2.0);
+    const double f32 = MFMA_PER_IT * 32768.0;      // 48 MFMAs of 32x32x16
+    const double f16 = 2 * 24 * 2 * 16384.0;       // two halves x 24 steps x 2 MFMAs of 16x16x32 (same flops)
+    run(mfma_loop<0>, f32, "32x32x16, registers, zeros", d_zero, d_sink, grid, 2.0);
+    run(mfma_loop<0>, f32, "32x32x16, registers, random N(0,1) bf16", d_rand, d_sink, grid, 2.0);
+    run(mfma_loop<1>, f32, "32x32x16, A from LDS (ds_read_b128 per MFMA), zeros", d_zero, d_sink, grid, 2.0);
+    run(mfma_loop<1>, f32, "32x32x16, A from LDS (ds_read_b128 per MFMA), random N(0,1) bf16", d_rand, d_sink, grid, 2.0);
+    run(mfma_loop16<0>, f16, "16x16x32, registers, random N(0,1) bf16", d_rand, d_sink, grid, 2.0);
+    run(mfma_loop16<1>, f16, "16x16x32, A from LDS (ds_read_b128 per 2 MFMAs), zeros", d_zero, d_sink, grid, 2.0);
+    run(mfma_loop16<1>, f16, "16x16x32, A from LDS (ds_read_b128 per 2 MFMAs), random N(0,1) bf16", d_rand, d_sink, grid, 2.0);
     return 0;
 }
