@@ -172,7 +172,7 @@ def main():
     # the instance mips_search dispatches to for this shape (mips_hip.hip::launch_search); other shapes run
     # other instances of the same kernels, named in the rocprofv3 summary of that run
     if (d, k) == (768, 5) and nq > 256:
-        kernel_name = "mips::scan_kernel_f8<8, 768, 2>" if f8 else "mips::scan_kernel_v3<8, 48, 1, 2, true, 0, 2, 8, 3, true, false, 8>"
+        kernel_name = "mips::scan_kernel_f8<8, 768, 2>" if f8 else "mips::scan_kernel_v4<6, 24, 2, 0>"
     else:
         kernel_name = "mips::scan_kernel_f8<...>" if f8 else "mips::scan_kernel_v3<...> / mips::scan_kernel<...> (see DESIGN.md section 4)"
     roofline = {
