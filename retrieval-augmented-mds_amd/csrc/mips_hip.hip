@@ -267,11 +267,12 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // variant 3 (query-stationary, LDS-DMA): the whole K of a wave's 32 queries lives in its VGPRs, so it
     // exists for a few row lengths only: 256 / 512 / 768 (8 waves, 2 per SIMD) and 1024 (4 waves, 1 per SIMD)
     int variant = ix->opt_variant;
-    // scan_kernel_v4 (16x16x32 MFMA shape, 4 sub-lists of 6): d pads to 768, k <= 5, bf16 storage.  It is the default
+    // scan_kernel_v4 (16x16x32 MFMA shape, 4 sub-lists of 6): row pitch 384 .. 768 (at 256 the shorter chain no
+    // longer pays: 2.03 vs 2.00 ms), k <= 5, bf16 storage.  It is the default
     // there when more than one query tile shares the document stream (the MFMA-bound regime, where the shape's
     // higher clock pays: 4.54 vs 4.78 ms at BASELINE config 2); single-tile searches are HBM-bound and keep
     // scan_kernel_v3's non-temporal document DMA.  "variant" = 3 / 4 forces one of the two.
-    const bool v4_shape = ix->ld == 768 && KL == 8 && ix->esize == 2 && ix->plane == 0;
+    const bool v4_shape = ix->ld % 128 == 0 && ix->ld >= 384 && ix->ld <= 768 && KL == 8 && ix->esize == 2 && ix->plane == 0;
     const bool v4_forced = variant == 4 && v4_shape;
     const bool v4_auto = variant == 0 && ix->opt_sub == 0 && v4_shape;
     if (variant != 1 && variant != 3) variant = 3;
@@ -374,16 +375,20 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     const int slot = ix->ev_next;
     if (want_v4) {
         if constexpr (KL == 8) {
-            const int lds = 3 * mips::V3_DB * ix->ld * 2 + 8 * 1024 + 1024 + 16;
-            if (ix->opt_sub == 8) { // timing only: no epilogue
-                HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel_v4<V4_KLL, 24, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            const int lds = 3 * mips::V3_DB * ix->ld * 2 + 8 * 1024 + 1024 + 16; // ring + threshold words + dump area + arrival counter
+            auto go4 = [&](auto kern) -> int {
+                HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
                 HIP_TRY(hipEventRecord(ix->ev0[slot], st));
-                mips::scan_kernel_v4<V4_KLL, 24, 2, 1><<<grid, 512, lds, st>>>(a);
-            } else {
-                HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel_v4<V4_KLL, 24, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                HIP_TRY(hipEventRecord(ix->ev0[slot], st));
-                mips::scan_kernel_v4<V4_KLL, 24, 2><<<grid, 512, lds, st>>>(a);
-            }
+                kern<<<grid, 512, lds, st>>>(a);
+                return MIPS_OK;
+            };
+            int rc2;
+            if (ix->ld == 768 && ix->opt_sub == 8) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 1>); // timing only: no epilogue
+            else if (ix->ld == 768) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2>);
+            else if (ix->ld == 640) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 20, 2>);
+            else if (ix->ld == 512) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 16, 2>);
+            else rc2 = go4(mips::scan_kernel_v4<V4_KLL, 12, 2>);
+            if (rc2) return rc2;
         }
     } else if (f8) {
         if constexpr (KL <= 16) {
