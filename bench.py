@@ -172,9 +172,9 @@ def main():
     # the instance mips_search dispatches to for this shape (mips_hip.hip::launch_search); other shapes run
     # other instances of the same kernels, named in the rocprofv3 summary of that run
     if (d, k) == (768, 5) and nq > 256:
-        kernel_name = "mips::scan_kernel_f8<8, 768, 2>" if f8 else "mips::scan_kernel_v4<6, 24, 2, 0>"
+        kernel_name = "mips::scan_kernel_f8x<6, 768, 2, 0>" if f8 else "mips::scan_kernel_v4<6, 24, 2, 0>"
     else:
-        kernel_name = "mips::scan_kernel_f8<...>" if f8 else "mips::scan_kernel_v3<...> / mips::scan_kernel<...> (see DESIGN.md section 4)"
+        kernel_name = "mips::scan_kernel_f8x<...> / mips::scan_kernel_f8<...>" if f8 else "mips::scan_kernel_v3<...> / mips::scan_kernel<...> (see DESIGN.md section 4)"
     roofline = {
         "bound": "mfma", "achieved": ach_tflops, "peak": PEAK_FP8_TFLOPS if f8 else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": ach_tflops / (PEAK_FP8_TFLOPS if f8 else PEAK_BF16_TFLOPS), "traffic": traffic, "traffic_source": traffic_src,

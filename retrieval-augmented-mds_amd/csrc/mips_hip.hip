@@ -15,6 +15,7 @@
 #include "scan_kernel.hpp"
 #include "scan_kernel_v3.hpp"
 #include "scan_kernel_f8.hpp"
+#include "scan_kernel_f8x.hpp"
 #include "scan_kernel_v4.hpp"
 
 namespace {
@@ -291,13 +292,16 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // Longer lists or d = 1024 do not fit next to the fragments there: 4 waves, one per SIMD, 512 registers,
     // 128 queries per workgroup.
     const int v3_waves = (!f8 && (ix->ld == 1024 || !kl_short)) ? 4 : 8;
-    const int tm = variant == 1 ? mips::TM : mips::V3_DB;             // documents per scheduling unit ("tile")
+    // fp8: scan_kernel_f8x (16x16x128 MFMA shape, 64-document blocks, 4 sub-lists of 6) for k <= 5 and row pitches
+    // up to 768 bytes; scan_kernel_f8 (32x32x64, 32-document blocks) otherwise or when "variant" = 3 asks for it
+    const bool want_f8x = f8 && KL == 8 && ix->ld <= 768 && ix->opt_variant != 3;
+    const int tm = variant == 1 ? mips::TM : want_f8x ? mips::F8X_DB : mips::V3_DB; // documents per scheduling unit ("tile")
     const int tn = variant == 1 ? mips::TN : v3_waves * 32;           // queries per workgroup
     const int wg_target = variant == 1 ? 512 : 256;                   // resident workgroups on 256 CUs
     const int64_t nq_pad = round_up(nq, kQueryAlign);
     const int nqt = (int)((nq + tn - 1) / tn);
     const bool want_v4 = v4_forced || (v4_auto && nqt > 1);
-    const int lists = want_v4 ? 4 : 2;                                // running lists per (query, split)
+    const int lists = (want_v4 || want_f8x) ? 4 : 2;                  // running lists per (query, split)
     const int ntiles = (int)((ix->ntotal + tm - 1) / tm);
     // Index splits (a multiple of 8: one XCD group each).  The grid nqt x nsplit should come in whole
     // "rounds" of wg_target resident workgroups: among the multiples of 8 up to 64 take the one whose last
@@ -335,7 +339,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // still the K' = 8 best of their union
     constexpr int V4_KLL = 6;
     const bool short_lists = !want_v4 && KL == 8 && variant == 3 && !f8 && ix->ld == 768 && (ix->opt_sub == 10 || ix->opt_sub == 11);
-    const size_t ncand = (size_t)nsplit * lists * ((want_v4 || short_lists) ? V4_KLL : KL);
+    const size_t ncand = (size_t)nsplit * lists * ((want_v4 || want_f8x || short_lists) ? V4_KLL : KL);
     int rc = ix->part_s.ensure((size_t)nq_pad * ncand * sizeof(float));
     if (rc) return rc;
     rc = ix->part_i.ensure((size_t)nq_pad * ncand * sizeof(int));
@@ -388,6 +392,26 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             else if (ix->ld == 640) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 20, 2>);
             else if (ix->ld == 512) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 16, 2>);
             else rc2 = go4(mips::scan_kernel_v4<V4_KLL, 12, 2>);
+            if (rc2) return rc2;
+        }
+    } else if (want_f8x) {
+        if constexpr (KL == 8) {
+            mips::ScanArgsF8 fa;
+            fa.docs = ix->rows;
+            fa.qbuf = (const uint8_t*)ix->qbuf.p;
+            fa.c = a;
+            const int lds = 3 * mips::F8X_DB * ix->ld + 8 * 1024 + 1024 + 16; // ring + threshold words + dump area + arrival counter
+            auto gox = [&](auto kern) -> int {
+                HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                HIP_TRY(hipEventRecord(ix->ev0[slot], st));
+                kern<<<grid, 512, lds, st>>>(fa);
+                return MIPS_OK;
+            };
+            int rc2;
+            if (ix->ld == 768 && ix->opt_sub == 8) rc2 = gox(mips::scan_kernel_f8x<V4_KLL, 768, 2, 1>); // timing only: no epilogue
+            else if (ix->ld == 768) rc2 = gox(mips::scan_kernel_f8x<V4_KLL, 768, 2>);
+            else if (ix->ld == 512) rc2 = gox(mips::scan_kernel_f8x<V4_KLL, 512, 2>);
+            else rc2 = gox(mips::scan_kernel_f8x<V4_KLL, 256, 2>);
             if (rc2) return rc2;
         }
     } else if (f8) {

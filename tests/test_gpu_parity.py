@@ -610,6 +610,24 @@ def test_fp8_index_parity(n, nq, d, k):
         assert np.array_equal(s, es)
 
 
+def test_fp8_scan_kernels_are_bit_identical():
+    """The fp8 index has two scan kernels: scan_kernel_f8x (16x16x128 MFMA shape, 64-document blocks; default
+    for k <= 5 and d <= 768) and scan_kernel_f8 (32x32x64; "variant" = 3 forces it).  Same bits, ragged sizes
+    and single- / multi-tile query counts included."""
+    for n, nq, d in ((150001, 700, 768), (64 * 37 + 5, 40, 768), (20000, 300, 512), (7001, 9, 200)):
+        ix = ram.MipsIndex(d, dtype="fp8_e4m3")
+        ix.add_synthetic(n, row0=0, seed=181, kind=synth.KIND_GAUSS)
+        q = ram.synth_fill(nq, d, 0, 182, synth.KIND_GAUSS)
+        ref_s, ref_i = ix.search(q, 5)
+        ix.set_param("variant", 3)
+        s, i = ix.search(q, 5)
+        assert torch.equal(i, ref_i) and torch.equal(s, ref_s), (n, nq, d)
+        ix.set_param("variant", 0)
+        ix.set_param("nsplit", 40)
+        s, i = ix.search(q, 5)
+        assert torch.equal(i, ref_i) and torch.equal(s, ref_s), (n, nq, d)
+
+
 def test_fp8_index_l2_padding_limits_and_persistence(tmp_path):
     x = synth.generate(121, 0, 2000, 768, synth.KIND_GAUSS)
     q = synth.generate(122, 0, 5, 768, synth.KIND_GAUSS)

@@ -131,6 +131,66 @@ __global__ __launch_bounds__(512, 2) void mfma_loop16(const uint16_t* src, float
     if (t == 12345.678f) sink[0] = t;
 }
 
+// ---- fp8 (e4m3) on the block-scaled f8f6f4 instructions with unit scales, same structure: 32x32x64 (one 32-byte
+// A fragment per MFMA, two ds_read_b128) against 16x16x128 (one 32-byte A fragment per TWO MFMAs).
+typedef int v8i32 __attribute__((ext_vector_type(8)));
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+constexpr int NFRAG8 = 8; // 64 VGPRs of B fragments
+
+template <int MODE, int SHAPE> // SHAPE 0: 32x32x64, 1: 16x16x128
+__global__ __launch_bounds__(512, 2) void mfma_loop_f8(const uint16_t* src, float* sink, int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[48 * 1024];
+    const int lane = threadIdx.x & 63;
+    v8i32 b[NFRAG8], a[2];
+    const uint16_t* base = src + ((size_t)blockIdx.x * 512 + threadIdx.x) * 8;
+#pragma unroll
+    for (int i = 0; i < NFRAG8; ++i) {
+        const v4i32 lo = *reinterpret_cast<const v4i32*>(base + (size_t)(2 * i) * 512 * 8 * gridDim.x);
+        const v4i32 hi = *reinterpret_cast<const v4i32*>(base + (size_t)(2 * i + 1) * 512 * 8 * gridDim.x);
+        b[i] = v8i32{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+    a[0] = b[3];
+    a[1] = b[5];
+    if (MODE == 1) {
+        for (int o = threadIdx.x * 16; o < 48 * 1024; o += 512 * 16)
+            *reinterpret_cast<v4i32*>(lds + o) = *reinterpret_cast<const v4i32*>(src + (o / 2) % 4096 + (size_t)blockIdx.x * 4096);
+        __syncthreads();
+    }
+    f32x16 acc32;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc32[r] = 0.f;
+    const int off = (lane * 32) % (16 * 1024);
+    for (int it = 0; it < iters; ++it) {
+        // 24 KiB "block" of 32 rows x 768 bytes = 12 steps of 32x32x64 or 2 halves x 6 steps x 2 MFMAs of 16x16x128
+#pragma unroll
+        for (int s = 0; s < 12; ++s) {
+            v8i32 av = a[s & 1];
+            if (MODE == 1) {
+                const v4i32 lo = *reinterpret_cast<const v4i32*>(lds + off + s * 2048);
+                const v4i32 hi = *reinterpret_cast<const v4i32*>(lds + off + s * 2048 + 16);
+                av = v8i32{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            if (SHAPE == 0) {
+                acc32 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, b[s % NFRAG8], acc32, 0, 0, 0, 0, 0, 0);
+            } else {
+                acc0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, b[s % NFRAG8], acc0, 0, 0, 0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, b[(s + 3) % NFRAG8], acc1, 0, 0, 0, 0, 0, 0);
+            }
+        }
+        if ((it & 63) == 63) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc32[r] *= 1e-6f;
+            acc0 *= 1e-6f;
+            acc1 *= 1e-6f;
+        }
+    }
+    float t = acc0[0] + acc1[0] + acc0[3] + acc1[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += acc32[r];
+    if (t == 12345.678f) sink[0] = t;
+}
+
 static uint64_t mix(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -200,5 +260,21 @@ int main() {
     run(mfma_loop16<0>, f16, "16x16x32, registers, random N(0,1) bf16", d_rand, d_sink, grid, 2.0);
     run(mfma_loop16<1>, f16, "16x16x32, A from LDS (ds_read_b128 per 2 MFMAs), zeros", d_zero, d_sink, grid, 2.0);
     run(mfma_loop16<1>, f16, "16x16x32, A from LDS (ds_read_b128 per 2 MFMAs), random N(0,1) bf16", d_rand, d_sink, grid, 2.0);
+    // fp8: reinterpret the random bf16 bit patterns as e4m3 bytes, NaN codes (0x7f / 0xff) cleared
+    {
+        uint8_t* hb = (uint8_t*)h;
+        for (size_t i = 0; i < n * 2; ++i) {
+            hb[i] = (uint8_t)(mix(i) >> 17);
+            if ((hb[i] & 0x7f) == 0x7f) hb[i] &= 0x77;
+        }
+        CHECK(hipMemcpy(d_rand, h, n * 2, hipMemcpyHostToDevice));
+    }
+    const double f8a = 12 * 2.0 * 32 * 32 * 64;        // 12 MFMAs of 32x32x64
+    const double f8b = 12 * 2 * 2.0 * 16 * 16 * 128;   // 12 steps x 2 MFMAs of 16x16x128 (same flops)
+    run(mfma_loop_f8<0, 0>, f8a, "fp8 32x32x64, registers, random e4m3 bytes", d_rand, d_sink, grid, 2.0);
+    run(mfma_loop_f8<1, 0>, f8a, "fp8 32x32x64, A from LDS (2 ds_read_b128 per MFMA), random e4m3 bytes", d_rand, d_sink, grid, 2.0);
+    run(mfma_loop_f8<0, 1>, f8b, "fp8 16x16x128, registers, random e4m3 bytes", d_rand, d_sink, grid, 2.0);
+    run(mfma_loop_f8<1, 1>, f8b, "fp8 16x16x128, A from LDS (2 ds_read_b128 per 2 MFMAs), random e4m3 bytes", d_rand, d_sink, grid, 2.0);
+    run(mfma_loop_f8<1, 1>, f8b, "fp8 16x16x128, A from LDS, zeros", d_zero, d_sink, grid, 2.0);
     return 0;
 }
