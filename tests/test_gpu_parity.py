@@ -610,6 +610,45 @@ def test_fp8_index_parity(n, nq, d, k):
         assert np.array_equal(s, es)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp8_e4m3"])
+def test_duplicates_crowding_one_sub_list(dtype):
+    """Worst case for the 16x16 kernels' sub-lists (4 per (query, split), 6 entries each): many IDENTICAL best
+    documents whose rows all fall into the same sub-list (stride 16 inside one split).  Their scores tie
+    exactly, the strict '>' keeps the lowest indices, and the top 5 are the 5 lowest-index copies."""
+    n, d, nq = 40000, 768, 300
+    kind = synth.KIND_LATTICE_FP8 if dtype != "bf16" else synth.KIND_GAUSS
+    x = synth.generate(191, 0, n, d, kind)
+    q = synth.generate(192, 0, nq, d, kind)
+    star = np.abs(synth.generate(193, 0, 1, d, kind)[0]) + 1.0       # large positive entries: beats every random row
+    if dtype != "bf16":
+        star = synth.round_to_e4m3(star)
+    rows = 1003 + 16 * np.arange(40)
+    x[rows] = star
+    q[::7] = star                                                     # these queries have 40 tied best documents
+    ix = ram.MipsIndex(d, dtype=dtype)
+    ix.add(x)
+    stored = synth.bf16_bits_to_f32(ix.rows_bf16()) if dtype == "bf16" else synth.e4m3_bits_to_f32(ix.rows_raw())
+    qq = synth.round_to_bf16(q) if dtype == "bf16" else synth.round_to_e4m3(q)   # what the device scores with
+    tied = np.arange(0, nq, 7)
+    free = np.setdiff1d(np.arange(nq), tied)
+    es, ei = orc.search_exact(qq[free], stored, 5)                    # tie-free queries: the fast oracle
+    ts, ti = orc.search_exact_bruteforce(qq[tied[:6]], stored, 5)     # tied ones: full enumeration (tie-safe), a few
+    assert np.array_equal(ti, np.tile(rows[:5], (6, 1)))
+    for variant in (0, 3, 4):
+        ix.set_param("variant", variant)
+        s, i = ix.search(q, 5)
+        assert np.array_equal(i[tied], np.tile(rows[:5], (len(tied), 1))), variant
+        assert np.array_equal(s[tied[:6]], ts) and (s[tied] == s[tied[0], 0]).all(), variant
+        # the other queries may rank the 40 copies among their best as well: the fast oracle is not tie-safe, so
+        # compare scores everywhere, indices where no copy is involved, and demand the LOWEST copies otherwise
+        assert np.array_equal(s[free], es), variant
+        copy_g, copy_o = np.isin(i[free], rows), np.isin(ei, rows)
+        assert np.array_equal(copy_g, copy_o) and np.array_equal(i[free][~copy_g], ei[~copy_o]), variant
+        for row_i, row_c in zip(i[free], copy_g):
+            m = int(row_c.sum())
+            assert np.array_equal(row_i[row_c], rows[:m]), variant
+
+
 def test_fp8_scan_kernels_are_bit_identical():
     """The fp8 index has two scan kernels: scan_kernel_f8x (16x16x128 MFMA shape, 64-document blocks; default
     for k <= 5 and d <= 768) and scan_kernel_f8 (32x32x64; "variant" = 3 forces it).  Same bits, ragged sizes
