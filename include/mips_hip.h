@@ -18,9 +18,10 @@
  *     HOST output buffers synchronise that stream before returning.
  *   - one index lives on one GPU.  Concurrent calls on one index (from several host
  *     threads) must be serialised by the caller (the Python wrapper holds a lock).  Calls
- *     issued on different streams are ordered by the library: a call waits, on its own
- *     stream, for an event recorded at the end of the previous call on that index, so
- *     the shared scratch is never used by two in-flight searches.
+ *     issued on different streams are ordered by the library: a call arriving on another
+ *     stream than the previous one records an event on that previous stream and waits for
+ *     it, so the shared scratch is never used by two in-flight searches (a stream handed
+ *     to the library must stay valid until the next call on the index).
  *   - ties: the lowest document index wins (the reference leaves ties undefined).
  *   - padding (FAISS IndexFlat convention): when k > ntotal the tail of every row is
  *     idx = -1, score = -inf (inner product) or +inf (L2).
@@ -195,10 +196,11 @@ int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out
  * (profiles/ experiment logs).  Results never depend on them; only speed does. */
 int mips_index_set_param(mips_index_t* index, const char* name, int64_t value);
 
-/* Timing hook used by bench.py: every mips_search records a HIP event pair around its fused scan
- * kernel on the search stream (a ring of 128 pairs).  Returns the summed duration in ms and the
- * number of scan launches recorded since the last reset (at most 128); the stream must have been
- * synchronised.  reset != 0 starts a new measurement window. */
+/* Timing hook used by bench.py.  reset != 0 opens a measurement window: from then on every
+ * mips_search records a HIP event pair around its fused scan kernel on the search stream (at most
+ * 128 pairs; recording stops when the window is full -- an event pair costs ~11 us of stream time,
+ * which is why it is off outside a window).  Returns the summed duration in ms and the number of
+ * scan launches recorded in the current window; the stream must have been synchronised. */
 int mips_scan_timing(mips_index_t* index, float* out_sum_ms, int* out_count, int reset);
 
 #ifdef __cplusplus

@@ -405,7 +405,7 @@ __global__ __launch_bounds__(64) void rescore_rank_kernel(MergeArgs p, const int
     if (valid) {
         const typename EL::type* x = reinterpret_cast<const typename EL::type*>(p.docs) + (size_t)ci * p.ld;
         const typename EL::type* y = reinterpret_cast<const typename EL::type*>(p.qbuf) + (size_t)q * p.ld;
-        constexpr int PF = 4;
+        constexpr int PF = 24; // 16-byte chunks in flight per row: the kernel is one latency-bound thread per candidate
         const int nchunk = p.ld / EL::PER16;
         u32x4 xr[PF], yr[PF];
 #pragma unroll

@@ -213,14 +213,17 @@ class MipsIndex:
         _lib.check(self._lib.mips_index_set_param(self._h, name.encode(), int(value)), "mips_index_set_param")
 
     def scan_timing(self, reset: bool = False):
-        """(summed ms, launches) of the fused scan kernel since the last reset, from HIP events on
-        the search stream (synchronise first)."""
+        """(summed ms, launches) of the fused scan kernel in the current measurement window, from HIP events
+        on the search stream (synchronise first).  reset=True opens a new window (at most 128 launches);
+        outside a window no events are recorded."""
         ms, cnt = ctypes.c_float(), ctypes.c_int()
         _lib.check(self._lib.mips_scan_timing(self._h, ctypes.byref(ms), ctypes.byref(cnt), int(reset)),
                    "mips_scan_timing")
         return ms.value, cnt.value
 
     def last_scan_ms(self) -> float:
+        """Mean scan-kernel time of the searches since scan_timing(reset=True) opened a measurement window
+        (-1.0 outside a window: events are not recorded then)."""
         import torch
 
         torch.cuda.synchronize(self.device)
