@@ -252,18 +252,20 @@ def search_exact(q: np.ndarray, x: np.ndarray, k: int, metric: int = METRIC_INNE
     # equals the smallest kept one is unnecessary for tie-free data; lattice data is
     # handled by search_exact_bruteforce (small sizes) instead.
     canon = canonical_pairs(q, x, best_i)                 # fp64
-    sc32 = canon.astype(np.float32)
-    order = _order_desc(sc32, best_i)
-    sc32 = np.take_along_axis(sc32, order, axis=1)[:, :k]
-    ids = np.take_along_axis(best_i, order, axis=1)[:, :k]
-    kk = sc32.shape[1]
     if metric == METRIC_L2:
+        # the L2 result is ordered by ITS float32 value (ascending, index ascending on ties): two documents
+        # whose inner products differ can round to the same distance next to |q|^2 + phi
         phi = sumsq_canonical(x).max()
         qn = sumsq_canonical(q)
-        c64 = np.take_along_axis(canon, order, axis=1)[:, :k]
-        out_s[:, :kk] = (qn[:, None] + phi - 2.0 * c64).astype(np.float32)
+        val = (qn[:, None] + phi - 2.0 * canon).astype(np.float32)
+        order = _order_desc(-val, best_i)
     else:
-        out_s[:, :kk] = sc32
+        val = canon.astype(np.float32)
+        order = _order_desc(val, best_i)
+    val = np.take_along_axis(val, order, axis=1)[:, :k]
+    ids = np.take_along_axis(best_i, order, axis=1)[:, :k]
+    kk = val.shape[1]
+    out_s[:, :kk] = val
     out_i[:, :kk] = ids + idx_offset
     return out_s, out_i
 
@@ -274,11 +276,13 @@ def search_exact_bruteforce(q, x, k, metric=METRIC_INNER_PRODUCT, idx_offset=0):
     q = np.ascontiguousarray(q, dtype=np.float32)
     x = np.ascontiguousarray(x, dtype=np.float32)
     nq, n = q.shape[0], x.shape[0]
-    out_s = np.empty((nq, k), dtype=np.float32)
-    out_i = np.empty((nq, k), dtype=np.int64)
-    if nq and k:
+    # L2: ranked by the float32 DISTANCE (see search_exact); fetch a few more by inner product, re-rank, cut
+    kf = k if metric != METRIC_L2 else min(max(n, k), k + 16)
+    out_s = np.empty((nq, kf), dtype=np.float32)
+    out_i = np.empty((nq, kf), dtype=np.int64)
+    if nq and kf:
         _c().oracle_search_exact(_p(q, ctypes.c_float), nq, _p(x, ctypes.c_float), n, q.shape[1] if q.ndim == 2 else 0,
-                                 k, _p(out_s, ctypes.c_float), _p(out_i, ctypes.c_int64))
+                                 kf, _p(out_s, ctypes.c_float), _p(out_i, ctypes.c_int64))
     if metric == METRIC_L2:
         phi = sumsq_canonical(x).max() if n else 0.0
         qn = sumsq_canonical(q)
@@ -286,7 +290,11 @@ def search_exact_bruteforce(q, x, k, metric=METRIC_INNER_PRODUCT, idx_offset=0):
         safe = np.where(valid, out_i, 0)
         ip = canonical_pairs(q, x, safe) if n else np.zeros(out_i.shape)
         d = (qn[:, None] + phi - 2.0 * ip).astype(np.float32)
-        out_s = np.where(valid, d, np.float32(np.inf)).astype(np.float32)
+        d = np.where(valid, d, np.float32(np.inf)).astype(np.float32)
+        key_i = np.where(valid, out_i, np.iinfo(np.int64).max)
+        order = _order_desc(-d, key_i)
+        out_s = np.take_along_axis(d, order, axis=1)[:, :k]
+        out_i = np.take_along_axis(out_i, order, axis=1)[:, :k]
     out_i = np.where(out_i >= 0, out_i + idx_offset, -1)
     return out_s, out_i
 

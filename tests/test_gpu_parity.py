@@ -649,6 +649,21 @@ def test_duplicates_crowding_one_sub_list(dtype):
             assert np.array_equal(row_i[row_c], rows[:m]), variant
 
 
+def test_l2_results_are_ordered_by_the_float32_distance():
+    """Found by tools/fuzz.py: two documents whose inner products differ can round to the SAME float32 distance
+    next to |q|^2 + phi; the order is then by index, not by the hidden inner product."""
+    n, nq, d, k = 47010, 526, 768, 16
+    x = synth.generate(7146, 0, n, d, synth.KIND_GAUSS)
+    q = synth.generate(8146, 0, nq, d, synth.KIND_GAUSS)
+    ix = ram.MipsIndex(d, metric=ram.METRIC_L2)
+    ix.add(x)
+    s, i = ix.search(q, k)
+    es, ei = orc.search_exact(q, x, k, metric=orc.METRIC_L2)
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+    ties = (np.diff(s, axis=1) == 0)
+    assert ties.any() and (np.diff(i, axis=1)[ties] > 0).all()       # the case does contain equal distances
+
+
 def test_fp8_scan_kernels_are_bit_identical():
     """The fp8 index has two scan kernels: scan_kernel_f8x (16x16x128 MFMA shape, 64-document blocks; default
     for k <= 5 and d <= 768) and scan_kernel_f8 (32x32x64; "variant" = 3 forces it).  Same bits, ragged sizes
