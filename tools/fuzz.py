@@ -12,6 +12,7 @@ from oracle import synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--big", action="store_true", help="multi-tile searches (nq > 256) over larger indexes: the 16x16 kernels' regime")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 t_end = time.time() + a.seconds
@@ -25,6 +26,9 @@ while time.time() < t_end:
     lattice = bool(rng.random() < 0.3)
     n = int(rng.integers(1, 3000 if lattice else 50000))
     nq = int(rng.integers(1, 40 if lattice else 700))
+    if a.big and not lattice:
+        n, nq = int(rng.integers(50000, 300000)), int(rng.integers(257, 1500))
+        d = int(rng.choice([384, 512, 640, 700, 768, 768, 768, 1024]))
     kmax = 13 if dtype == "fp8_e4m3" else ram.MAX_K
     k = int(rng.choice([1, 2, 3, 5, 5, 5, 6, 7, 8, 10, 13, min(kmax, 16), kmax]))
     metric = int(rng.choice([ram.METRIC_IP, ram.METRIC_IP, ram.METRIC_L2]))
