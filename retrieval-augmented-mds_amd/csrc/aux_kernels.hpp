@@ -247,19 +247,23 @@ __global__ void synth_fill_kernel(void* out, int64_t n, int d, int ld, int64_t r
 template <typename EL>
 __global__ void row_sumsq_max_kernel(const typename EL::type* rows, int64_t n, int ld, unsigned long long* out_bits) {
     const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const typename EL::type* x = rows + r * ld;
-    double acc = 0.0;
-    for (int c = 0; c < ld; c += EL::PER16) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(x + c);
+    double acc = 0.0; // rows past the end contribute 0 (the maximum of non-negative values is unaffected)
+    if (r < n) {
+        const typename EL::type* x = rows + r * ld;
+        for (int c = 0; c < ld; c += EL::PER16) { // sequential in the column index: the oracle's order
+            const u32x4 v = *reinterpret_cast<const u32x4*>(x + c);
 #pragma unroll
-        for (int e = 0; e < EL::PER16; ++e) {
-            const double a = (double)EL::get(v, e);
-            acc += a * a;
+            for (int e = 0; e < EL::PER16; ++e) {
+                const double a = (double)EL::get(v, e);
+                acc += a * a;
+            }
         }
     }
-    // non-negative doubles order like their bit patterns
-    atomicMax(out_bits, (unsigned long long)__double_as_longlong(acc));
+    // one atomic per wave, not per row (a million atomics on one word take ~12 ms): the maximum is exact in any
+    // order; non-negative doubles order like their bit patterns
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc = fmax(acc, __shfl_xor(acc, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(acc));
 }
 
 // ------------------------------------------------------------------ row L2 normalisation (fp32, in place)
@@ -283,15 +287,18 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(float* x, int64_t n, 
 // max over rows of |x|^2 for fp32 rows (fp64 accumulation); max_norm of mips.py:298-304 is its sqrt
 __global__ __launch_bounds__(256) void f32_rows_max_sumsq_kernel(const float* x, int64_t n, int d,
                                                                  unsigned long long* out_bits) {
-    const int64_t row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    // a wave takes rows blockIdx.x * 4 + wave, + 4 gridDim.x, ... and keeps a running maximum: one atomic per wave
     const int lane = threadIdx.x & 63;
-    if (row >= n) return;
-    const float* r = x + row * d;
-    double acc = 0.0;
-    for (int c = lane; c < d; c += 64) acc += (double)r[c] * (double)r[c];
+    double best = 0.0;
+    for (int64_t row = blockIdx.x * 4ll + (threadIdx.x >> 6); row < n; row += 4ll * gridDim.x) {
+        const float* r = x + row * d;
+        double acc = 0.0;
+        for (int c = lane; c < d; c += 64) acc += (double)r[c] * (double)r[c];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if (lane == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(acc));
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        best = fmax(best, acc);
+    }
+    if (lane == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(best));
 }
 
 // ------------------------------------------------------------------ split merge + exact re-score

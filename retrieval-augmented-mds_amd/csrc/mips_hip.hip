@@ -892,7 +892,7 @@ int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out
     HIP_TRY(hipMalloc((void**)&slot, 8));
     hipError_t e = hipMemsetAsync(slot, 0, 8, st);
     if (e == hipSuccess) {
-        mips::f32_rows_max_sumsq_kernel<<<(int)((n + 3) / 4), 256, 0, st>>>(x_device, n, (int)d, slot);
+        mips::f32_rows_max_sumsq_kernel<<<(int)std::min<int64_t>((n + 3) / 4, 256 * 16), 256, 0, st>>>(x_device, n, (int)d, slot);
         e = hipGetLastError();
     }
     unsigned long long bits = 0;
