@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void mfma_loop(const uint16_t* src, float* 
 
 // The 16x16x32 shape at the same bytes and flops per wave: per step ONE A fragment (16 documents x 32 k, from
 // registers or LDS) feeds two MFMAs (two 16-query column blocks), as scan_kernel_v4 does.  MODE as above.
-template <int MODE>
+template <int MODE, bool B_IN_AGPR = false>
 __global__ __launch_bounds__(512, 2) void mfma_loop16(const uint16_t* src, float* sink, int iters) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[48 * 1024];
     const int lane = threadIdx.x & 63;
@@ -89,6 +89,12 @@ __global__ __launch_bounds__(512, 2) void mfma_loop16(const uint16_t* src, float
     for (int i = 0; i < NFRAG; ++i) b[i] = *reinterpret_cast<const bf16x8*>(base + (size_t)i * 512 * 8 * gridDim.x);
     a[0] = b[3];
     a[1] = b[7];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (B_IN_AGPR) { // stationary B fragments in the accumulation half of the register file (MFMA reads them there directly)
+#pragma unroll
+        for (int i = 0; i < NFRAG; ++i) asm volatile("" : "+a"(b[i]));
+    }
+#endif
     if (MODE == 1) {
         for (int o = threadIdx.x * 16; o < 48 * 1024; o += 512 * 16)
             *reinterpret_cast<bf16x8*>(lds + o) = *reinterpret_cast<const bf16x8*>(src + (o / 2) % 4096 + (size_t)blockIdx.x * 4096);
@@ -260,6 +266,8 @@ int main() {
     run(mfma_loop16<0>, f16, "16x16x32, registers, random N(0,1) bf16", d_rand, d_sink, grid, 2.0);
     run(mfma_loop16<1>, f16, "16x16x32, A from LDS (ds_read_b128 per 2 MFMAs), zeros", d_zero, d_sink, grid, 2.0);
     run(mfma_loop16<1>, f16, "16x16x32, A from LDS (ds_read_b128 per 2 MFMAs), random N(0,1) bf16", d_rand, d_sink, grid, 2.0);
+    run(mfma_loop16<1, true>, f16, "16x16x32, A from LDS, B fragments in AGPRs, random N(0,1) bf16", d_rand, d_sink, grid, 2.0);
+    run(mfma_loop16<1>, f16, "16x16x32, A from LDS (repeat), random N(0,1) bf16", d_rand, d_sink, grid, 2.0);
     // fp8: reinterpret the random bf16 bit patterns as e4m3 bytes, NaN codes (0x7f / 0xff) cleared
     {
         uint8_t* hb = (uint8_t*)h;
