@@ -649,6 +649,32 @@ def test_duplicates_crowding_one_sub_list(dtype):
             assert np.array_equal(row_i[row_c], rows[:m]), variant
 
 
+def test_device_search_is_graph_capturable():
+    """A device-in / device-out search in steady state (scratch already sized) issues only stream operations, so
+    a caller may capture it into a HIP graph (torch.cuda.graph) and replay it with new query values."""
+    ix = ram.MipsIndex(768)
+    ix.add_synthetic(30000, 0, synth.SEED_DOCS, synth.KIND_GAUSS)
+    q = ram.synth_fill(40, 768, 0, 21, synth.KIND_GAUSS)
+    q2 = ram.synth_fill(40, 768, 0, 22, synth.KIND_GAUSS)
+    ref1, ref2 = ix.search(q, 5), ix.search(q2, 5)
+    torch.cuda.synchronize()
+    buf = q.clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                    # warm-up off the default stream, as torch asks for
+        ix.search(buf, 5)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        s, i = ix.search(buf, 5)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(i, ref1[1]) and torch.equal(s, ref1[0])
+    buf.copy_(q2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(i, ref2[1]) and torch.equal(s, ref2[0])
+
+
 def test_l2_results_are_ordered_by_the_float32_distance():
     """Found by tools/fuzz.py: two documents whose inner products differ can round to the SAME float32 distance
     next to |q|^2 + phi; the order is then by index, not by the hidden inner product."""
