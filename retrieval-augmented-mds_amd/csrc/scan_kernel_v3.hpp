@@ -1,11 +1,14 @@
-// scan_kernel_v3: query-stationary fused score + top-K scan (the fast path for d <= 768).
+// scan_kernel_v3: query-stationary fused score + top-K scan on v_mfma_f32_32x32x16_bf16.
+// The structure every scan kernel of this library shares (scan_kernel_v4 = the same scan on the 16x16x32 shape, the
+// default for multi-tile searches with k <= 5 at row pitches 384 .. 768; scan_kernel_f8 / f8x = fp8).  This instance
+// serves single-tile searches (HBM-bound, non-temporal document DMA), k = 6 .. 29, row pitches 128 / 256 and 1024.
 //
 // This problem is a GEMM with a tiny K (d = 768) and an enormous M (the index): instead of tiling it
 // like a square GEMM, every wave keeps the MFMA B-fragments of ITS 32 queries for the WHOLE K in
 // registers (KS16 = d/16 fragments x 4 VGPRs = 192 VGPRs at d = 768) for the lifetime of the
 // workgroup.  8 waves = 256 stationary queries per workgroup.  Only documents move:
 //   HBM/L2 -> LDS  by global_load_lds_dwordx4 (LDS-DMA), 32-document blocks (32 x d x 2 B = 48 KiB) in
-//                  a 3-deep ring, two blocks ahead, completion by counted s_waitcnt vmcnt + raw s_barrier;
+//                  a 3-deep ring, two blocks ahead, completion by counted s_waitcnt vmcnt + an LDS arrival counter;
 //   LDS -> MFMA    one ds_read_b128 (A fragment: 32 docs x 16 k) per v_mfma_f32_32x32x16_bf16.
 // Per CU and per 32-document block this is 48 KiB of fill for 2 x 48 x 32 = 3072 MFMA cycles per SIMD
 // = 16 B/clk, half of what a 256 x 256 GEMM tile needs and inside what the L2 -> LDS path of a CU
