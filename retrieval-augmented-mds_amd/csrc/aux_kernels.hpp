@@ -79,10 +79,18 @@ struct ElemF8 {
 
 // ------------------------------------------------------------------ conversion into [rows][ld] bf16
 // one thread per 8 output elements; columns >= d are written as zero.
+// Query staging folds two memsets into this launch: rows n .. n_out - 1 are written as zero (the padding up to the
+// query-tile multiple) and `zero_words` 32-bit words at `zero` are cleared (the shared insert bounds of the scan).
+__device__ __forceinline__ void zero_words_grid_stride(uint32_t* zero, int64_t zero_words) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < zero_words; t += (int64_t)gridDim.x * blockDim.x) zero[t] = 0u;
+}
+
 template <typename SRC>
-__global__ void convert_rows_kernel(const SRC* __restrict__ src, int64_t n, int d, uint16_t* dst, int ld) {
+__global__ void convert_rows_kernel(const SRC* __restrict__ src, int64_t n, int d, uint16_t* dst, int ld, int64_t n_out = 0,
+                                    uint32_t* zero = nullptr, int64_t zero_words = 0) {
     const int chunks = ld / 8;
-    const int64_t total = n * chunks;
+    const int64_t total = (n_out > n ? n_out : n) * chunks;
+    zero_words_grid_stride(zero, zero_words);
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
          t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = t / chunks;
@@ -91,7 +99,7 @@ __global__ void convert_rows_kernel(const SRC* __restrict__ src, int64_t n, int 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = c0 + e;
-            if (c < d) {
+            if (c < d && row < n) {
                 if constexpr (sizeof(SRC) == 4)
                     v[e] = f32_to_bf16_rne(((const float*)src)[row * d + c]);
                 else
@@ -111,9 +119,11 @@ __global__ void convert_rows_kernel(const SRC* __restrict__ src, int64_t n, int 
 
 // conversion into [rows][ld] e4m3 bytes; SRC = float, uint16_t (bf16 bits) or uint8_t (raw e4m3)
 template <typename SRC>
-__global__ void convert_rows_f8_kernel(const SRC* __restrict__ src, int64_t n, int d, uint8_t* dst, int ld) {
+__global__ void convert_rows_f8_kernel(const SRC* __restrict__ src, int64_t n, int d, uint8_t* dst, int ld, int64_t n_out = 0,
+                                       uint32_t* zero = nullptr, int64_t zero_words = 0) {
     const int chunks = ld / 16;
-    const int64_t total = n * chunks;
+    const int64_t total = (n_out > n ? n_out : n) * chunks;
+    zero_words_grid_stride(zero, zero_words);
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
          t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = t / chunks;
@@ -123,7 +133,7 @@ __global__ void convert_rows_f8_kernel(const SRC* __restrict__ src, int64_t n, i
         for (int e = 0; e < 16; ++e) {
             const int c = c0 + e;
             uint32_t b = 0;
-            if (c < d) {
+            if (c < d && row < n) {
                 if constexpr (sizeof(SRC) == 4) b = f32_to_e4m3(((const float*)src)[row * d + c]);
                 else if constexpr (sizeof(SRC) == 2) b = f32_to_e4m3(bf16_bits_to_f32(((const uint16_t*)src)[row * d + c]));
                 else b = ((const uint8_t*)src)[row * d + c];

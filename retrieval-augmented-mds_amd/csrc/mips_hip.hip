@@ -191,8 +191,11 @@ int grow(mips_index* ix, int64_t need_rows, hipStream_t st, bool exact = false) 
 }
 
 // convert [n][d] of src_dtype (host or device) into dst [n][ld] of the index element type on the device
+// pad_rows / zero / zero_words: query staging only -- that many zero rows behind the last converted one and a
+// word range to clear, both done by the launch that converts the last chunk (bf16 and fp8 storage)
 int convert_into(mips_index* ix, const void* src, int64_t n, int src_dtype, int src_is_device, uint8_t* dst,
-                 hipStream_t st, float* keep_f32 = nullptr) {
+                 hipStream_t st, float* keep_f32 = nullptr, int64_t pad_rows = 0, uint32_t* zero = nullptr,
+                 int64_t zero_words = 0) {
     const int d = (int)ix->d, ld = ix->ld;
     const size_t esz = src_dtype == MIPS_DTYPE_F32 ? 4 : src_dtype == MIPS_DTYPE_BF16 ? 2 : 1;
     const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(64u << 20) / (int64_t)(d * esz));
@@ -214,20 +217,26 @@ int convert_into(mips_index* ix, const void* src, int64_t n, int src_dtype, int 
                 mips::split_rows_kernel<float><<<grid_for(items, 256), 256, 0, st>>>((const float*)s, nr, d, d, (uint16_t*)out, ix->plane, keep);
             else
                 mips::split_rows_kernel<uint16_t><<<grid_for(items, 256), 256, 0, st>>>((const uint16_t*)s, nr, d, d, (uint16_t*)out, ix->plane, keep);
-        } else if (ix->esize == 2) {
-            const int64_t items = nr * (ld / 8);
-            if (src_dtype == MIPS_DTYPE_F32)
-                mips::convert_rows_kernel<float><<<grid_for(items, 256), 256, 0, st>>>((const float*)s, nr, d, (uint16_t*)out, ld);
-            else
-                mips::convert_rows_kernel<uint16_t><<<grid_for(items, 256), 256, 0, st>>>((const uint16_t*)s, nr, d, (uint16_t*)out, ld);
         } else {
-            const int64_t items = nr * (ld / 16);
-            if (src_dtype == MIPS_DTYPE_F32)
-                mips::convert_rows_f8_kernel<float><<<grid_for(items, 256), 256, 0, st>>>((const float*)s, nr, d, out, ld);
-            else if (src_dtype == MIPS_DTYPE_BF16)
-                mips::convert_rows_f8_kernel<uint16_t><<<grid_for(items, 256), 256, 0, st>>>((const uint16_t*)s, nr, d, out, ld);
-            else
-                mips::convert_rows_f8_kernel<uint8_t><<<grid_for(items, 256), 256, 0, st>>>((const uint8_t*)s, nr, d, out, ld);
+            const bool last = r0 + nr == n;
+            const int64_t n_out = nr + (last ? pad_rows : 0);
+            uint32_t* z = last ? zero : nullptr;
+            const int64_t zw = last ? zero_words : 0;
+            if (ix->esize == 2) {
+                const int64_t items = n_out * (ld / 8);
+                if (src_dtype == MIPS_DTYPE_F32)
+                    mips::convert_rows_kernel<float><<<grid_for(items, 256), 256, 0, st>>>((const float*)s, nr, d, (uint16_t*)out, ld, n_out, z, zw);
+                else
+                    mips::convert_rows_kernel<uint16_t><<<grid_for(items, 256), 256, 0, st>>>((const uint16_t*)s, nr, d, (uint16_t*)out, ld, n_out, z, zw);
+            } else {
+                const int64_t items = n_out * (ld / 16);
+                if (src_dtype == MIPS_DTYPE_F32)
+                    mips::convert_rows_f8_kernel<float><<<grid_for(items, 256), 256, 0, st>>>((const float*)s, nr, d, out, ld, n_out, z, zw);
+                else if (src_dtype == MIPS_DTYPE_BF16)
+                    mips::convert_rows_f8_kernel<uint16_t><<<grid_for(items, 256), 256, 0, st>>>((const uint16_t*)s, nr, d, out, ld, n_out, z, zw);
+                else
+                    mips::convert_rows_f8_kernel<uint8_t><<<grid_for(items, 256), 256, 0, st>>>((const uint8_t*)s, nr, d, out, ld, n_out, z, zw);
+            }
         }
         HIP_TRY(hipGetLastError());
         if (!src_is_device) HIP_TRY(hipStreamSynchronize(st));
@@ -370,9 +379,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     if (variant == 3) {
         // shared insert bounds: 8 class words per query (2 lane-half words in the older layouts) + error word
         const size_t thr_words = (size_t)nq_pad * 8;
-        rc = ix->gthr.ensure((thr_words + 4) * sizeof(unsigned));
-        if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(ix->gthr.p, 0, (thr_words + 4) * sizeof(unsigned), st));
+        // (allocated and cleared by mips_search together with the query staging)
         a.gthr = (unsigned*)ix->gthr.p;
         a.err = a.gthr + thr_words;
         ix->err_off = thr_words;
@@ -776,9 +783,20 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
             if (rc) return rc;
             qkeep = (float*)ix->qf32.p;
         }
-        rc = convert_into(ix, q, nq, q_dtype, (flags & MIPS_Q_DEVICE) ? 1 : 0, qb, st, qkeep);
+        // shared insert bounds of the scan: 8 class words per query + the error word
+        const int64_t thr_words = nq_pad * 8 + 4;
+        rc = ix->gthr.ensure((size_t)thr_words * sizeof(unsigned));
         if (rc) return rc;
-        if (nq_pad > nq) HIP_TRY(hipMemsetAsync(qb + (size_t)nq * row_bytes, 0, (size_t)(nq_pad - nq) * row_bytes, st));
+        if (ix->plane > 0) { // fp32-exact staging has its own kernel: clear with plain memsets
+            rc = convert_into(ix, q, nq, q_dtype, (flags & MIPS_Q_DEVICE) ? 1 : 0, qb, st, qkeep);
+            if (rc) return rc;
+            if (nq_pad > nq) HIP_TRY(hipMemsetAsync(qb + (size_t)nq * row_bytes, 0, (size_t)(nq_pad - nq) * row_bytes, st));
+            HIP_TRY(hipMemsetAsync(ix->gthr.p, 0, (size_t)thr_words * sizeof(unsigned), st));
+        } else { // one launch converts the queries, zero-pads to the tile multiple and clears the bounds
+            rc = convert_into(ix, q, nq, q_dtype, (flags & MIPS_Q_DEVICE) ? 1 : 0, qb, st, qkeep, nq_pad - nq,
+                              (uint32_t*)ix->gthr.p, thr_words);
+            if (rc) return rc;
+        }
         // K' = list length of the scan >= k + 3: the MFMA scores only SELECT candidates
         if (k <= 5)
             rc = launch_search<8>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st);
