@@ -270,3 +270,21 @@ def test_encode_shard_bounds_follow_the_reference_chunking():
                 assert (a, b) == (min(n, r * chunk), max(min(n, r * chunk), min(n, exp_stop)))
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert sum(b - a for a, b in spans) == n
+
+
+def test_bench_defaults_are_the_baseline_headline_config(monkeypatch):
+    """bench.py with no flags = BASELINE config 2 on one GPU (2^20 x 768 bf16, Q = 4096, k = 5); the timed path
+    must not import the oracle (only cpu_baseline() does)."""
+    import ast
+    import importlib
+    import sys as _sys
+
+    monkeypatch.setattr(_sys, "argv", ["bench.py"])
+    bench = importlib.import_module("bench")
+    a = bench.parse()
+    assert (a.gpus, a.rows, a.dim, a.queries, a.k, a.index_dtype) == (1, 1 << 20, 768, 4096, 5, "bf16")
+    assert a.steps >= 10 and a.warmup >= 1
+    tree = ast.parse(open(bench.__file__).read())
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        imports_oracle = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
+        assert imports_oracle == (fn.name == "cpu_baseline"), fn.name
