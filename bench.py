@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--index-dtype", default="bf16", choices=["bf16", "fp8_e4m3"],
                     help="fp8_e4m3 = BASELINE config 5 (index and queries quantised to OCP e4m3, fp8 MFMA)")
+    ap.add_argument("--no-pipeline", action="store_true", help="N > 1: run every step's all-gather + merge before the next scan")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N > 1 path on ONE GPU (all ranks on cuda:0, host-staged collective)")
     return ap.parse_args()
@@ -121,15 +122,48 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        s, i = index.search(q_dev, k)
+    # N > 1 over RCCL: consecutive steps are independent query batches, so the exchange step of batch t (the ONE
+    # all-gather + merge, on a side stream) overlaps the shard scan of batch t + 1 (ShardedMipsIndex.search_async).
+    # Every one of the K steps still completes inside the timed region.
+    pipelined = world > 1 and args.backend == "nccl" and not args.no_pipeline
+
+    def run_steps(count):
+        out = None
+        if pipelined:  # (read at call time: the fallback below may switch it off)
+            prev = None
+            for _ in range(count):
+                cur = index.search_async(q_dev, k)
+                if prev is not None:
+                    out = prev.result()
+                prev = cur
+            if prev is not None:
+                out = prev.result()
+        else:
+            for _ in range(count):
+                out = index.search(q_dev, k)
+        return out
+
+    try:
+        run_steps(args.warmup)
+        torch.cuda.synchronize()
+    except Exception as e:  # the overlapped exchange is an optimisation: never let it cost the measurement
+        if not pipelined:
+            raise
+        print(f"[bench] pipelined exchange failed on rank {rank} ({e!r}); using the synchronous path", file=sys.stderr, flush=True)
+        pipelined = False
+    if world > 1:  # all ranks must take the same path
+        flag = torch.tensor([1 if pipelined else 0], device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if pipelined and int(flag.item()) == 0:
+            pipelined = False
+        if not pipelined:
+            run_steps(args.warmup)
     torch.cuda.synchronize()
     barrier()
     index.local.scan_timing(reset=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        s, i = index.search(q_dev, k)
+    s, i = run_steps(args.steps)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -207,7 +241,7 @@ def main():
                                    f"resident in HBM, top-k={k}, exact; BASELINE config 2 at the defaults "
                                    f"(config 5 with --index-dtype fp8_e4m3)",
                        "index_rows": n, "dim": d, "queries": nq, "k": k,
-                       "parallelism": f"row-sharded x{world} + 1 all-gather" if world > 1 else "single GPU",
+                       "parallelism": (f"row-sharded x{world} + 1 all-gather" + (", exchange of step t overlapped with the scan of step t+1" if pipelined else "")) if world > 1 else "single GPU",
                        "rows_per_gpu": local_rows},
             "roofline": roofline, "cpu_baseline": cpu, "parity_vs_cpu_sample": parity,
             "index_build_s": t_build,

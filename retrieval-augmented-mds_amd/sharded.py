@@ -114,6 +114,59 @@ class ShardedMipsIndex:
     def ntotal(self) -> int:
         return self.ntotal_global
 
+    # ------------------------------------------------------------------ pipelined search
+    class _Pending:
+        """Result of search_async: .result() makes the CURRENT stream wait for the merged top-k and returns it."""
+
+        def __init__(self, out, done_event, keep):
+            self._out, self._done, self._keep = out, done_event, keep
+
+        def result(self):
+            import torch
+
+            if self._done is not None:
+                cur = torch.cuda.current_stream(self._out[0].device)
+                cur.wait_event(self._done)
+                for t in self._out:
+                    t.record_stream(cur)  # allocated on the side stream, consumed on this one
+                self._done, self._keep = None, None
+            return self._out
+
+    def search_async(self, q, k: int, _force_collective: bool = False):
+        """search() split in two: the local scan (+ select, exact re-score) is enqueued on the current stream,
+        the exchange step -- the ONE all-gather and the replicated merge -- on a side stream behind it, so the
+        caller can enqueue the NEXT batch's scan before asking for this batch's result().  Independent query
+        batches then overlap their exchange with the next scan (the collective is latency-bound: ~tens of us
+        against a ~0.6 ms shard scan at 8 GPUs).  Falls back to the synchronous path when there is nothing to
+        overlap (one rank, host queries, gloo)."""
+        import torch
+        import torch.distributed as dist
+
+        backend = dist.get_backend(self.group) if dist.is_initialized() else None
+        fast = (self.local is not None and self._fast and isinstance(q, torch.Tensor) and q.is_cuda
+                and backend == "nccl" and (self.world > 1 or _force_collective))
+        if not fast:
+            return ShardedMipsIndex._Pending(self.search(q, k), None, None)
+        from .index import merge_topk_packed
+
+        packed = self.local.search_packed(q, k, self.lo)  # current stream
+        nq = packed.shape[0]
+        main = torch.cuda.current_stream(q.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=q.device)
+        side = self._side
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            packed.record_stream(side)
+            gathered = torch.empty((self.world * nq, k, 2), dtype=torch.int64, device=packed.device)
+            dist.all_gather_into_tensor(gathered, packed, group=self.group)  # the ONE collective of the path
+            out = merge_topk_packed(gathered, nq, self.world, k, self.metric_type)
+            done = torch.cuda.Event()
+            done.record(side)
+        return ShardedMipsIndex._Pending(out, done, (packed, gathered))
+
     # ------------------------------------------------------------------ search
     def search(self, q, k: int):
         """Replicated queries in, global top-k out (same on every rank)."""

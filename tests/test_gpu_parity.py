@@ -649,6 +649,42 @@ def test_duplicates_crowding_one_sub_list(dtype):
             assert np.array_equal(row_i[row_c], rows[:m]), variant
 
 
+def _async_worker(rank, port, ret):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        sh = ram.ShardedMipsIndex(768, device=0)
+        sh.add_synthetic_global(60000, synth.SEED_DOCS, synth.KIND_GAUSS)
+        qs = [ram.synth_fill(300, 768, 0, 400 + t, synth.KIND_GAUSS) for t in range(6)]
+        refs = [sh.search(qq, 5) for qq in qs]                       # one rank: the plain local search
+        torch.cuda.synchronize()
+        # pipelined: every batch's scan is enqueued before any result is asked for; the exchange step (RCCL
+        # all-gather over the single rank + merge kernel) runs on the side stream
+        pend = [sh.search_async(qq, 5, _force_collective=True) for qq in qs]
+        ok = True
+        for p_, r_ in zip(pend, refs):
+            s, i = p_.result()
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(i, r_[1]) and torch.equal(s, r_[0])
+        ret["ok"] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_search_async_pipelines_the_exchange_step():
+    """ShardedMipsIndex.search_async: local scan on the caller's stream, all-gather + merge on a side stream;
+    checked here through a one-rank RCCL group (the multi-rank data path is the same call sequence)."""
+    import torch.multiprocessing as mp
+
+    ret = mp.Manager().dict()
+    mp.spawn(_async_worker, args=(29800 + (os.getpid() % 1500), ret), nprocs=1, join=True)
+    assert ret.get("ok") is True
+
+
 def test_device_search_is_graph_capturable():
     """A device-in / device-out search in steady state (scratch already sized) issues only stream operations, so
     a caller may capture it into a HIP graph (torch.cuda.graph) and replay it with new query values."""
