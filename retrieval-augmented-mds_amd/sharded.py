@@ -155,7 +155,7 @@ class ShardedMipsIndex:
         ready = torch.cuda.Event()
         ready.record(main)
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=q.device)
+            self._side = torch.cuda.Stream(device=q.device, priority=-1)  # its short kernels go first when CUs free up
         side = self._side
         with torch.cuda.stream(side):
             side.wait_event(ready)
