@@ -74,7 +74,22 @@ struct ElemF32 {
 struct ElemF8 {
     typedef uint8_t type;
     static constexpr int PER16 = 16;
-    __device__ static __forceinline__ float get(const u32x4& v, int e) { return e4m3_to_f32((v[e >> 2] >> ((e & 3) * 8)) & 0xffu); }
+    // v_cvt_f32_fp8 decodes OCP e4m3 on gfx950 (exact: every e4m3 value is an fp32 value); the byte selector is an
+    // immediate, hence the switch (it folds once the callers' loops are unrolled).  One instruction per element
+    // instead of ~10: the exact re-score of an fp8 index went from 138 to ~25 us per 4096 queries.
+    __device__ static __forceinline__ float get(const u32x4& v, int e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int w = (int)v[e >> 2];
+        switch (e & 3) {
+        case 0: return __builtin_amdgcn_cvt_f32_fp8(w, 0);
+        case 1: return __builtin_amdgcn_cvt_f32_fp8(w, 1);
+        case 2: return __builtin_amdgcn_cvt_f32_fp8(w, 2);
+        default: return __builtin_amdgcn_cvt_f32_fp8(w, 3);
+        }
+#else
+        return e4m3_to_f32((v[e >> 2] >> ((e & 3) * 8)) & 0xffu);
+#endif
+    }
 };
 
 // ------------------------------------------------------------------ conversion into [rows][ld] bf16
