@@ -243,7 +243,8 @@ def _gloo_worker(rank, world, port, n, nq, d, k, ret):
         ix.set_global_size(n)
         s, i = ix.search(q, k)
         es, ei = orc.search_exact_bruteforce(q, x, k)
-        ret[rank] = bool(np.array_equal(i, ei) and np.array_equal(s, es))
+        s2, i2 = ix.search_async(q, k).result()   # nothing to overlap on this backend: the synchronous path
+        ret[rank] = bool(np.array_equal(i, ei) and np.array_equal(s, es) and np.array_equal(i2, ei) and np.array_equal(s2, es))
     finally:
         dist.destroy_process_group()
 
