@@ -68,6 +68,13 @@ extern "C" {
 #define MIPS_E_HIP -2         /* a HIP runtime call failed */
 #define MIPS_E_UNSUPPORTED -3 /* valid request this build does not implement */
 #define MIPS_E_NOMEM -4       /* device allocation failed */
+#define MIPS_E_SCAN_TIMEOUT -5 /* a scan kernel gave up on its bounded block barrier: that search's output is poisoned */
+
+/* What a search whose scan kernel timed out writes into EVERY output slot instead of results: idx =
+ * MIPS_IDX_POISON (distinct from the -1 padding of k > ntotal), score = NaN.  mips_merge_topk(_packed) propagate
+ * it (a poisoned shard poisons the merged row), so the failure is visible on device-resident paths without any
+ * synchronisation; the host learns of it from the next call on the index or from mips_index_check_error. */
+#define MIPS_IDX_POISON (-2)
 
 #define MIPS_MAX_K 29 /* largest k one mips_search call accepts */
 
@@ -192,9 +199,29 @@ int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out
 /* Tuning knobs of the scan launch (0 = automatic): "nsplit" = number of index splits (rounded up
  * to a multiple of 8), "qgroups" = query-tile groups per XCD octet (1, 2, 4 or 8), "variant" = scan kernel (1 = 128x128
  * register-staged tiles, 3 = query-stationary on the 32x32x16 MFMA shape, 4 = query-stationary on the
- * 16x16x32 shape (d padding to 768, k <= 5)), "sub" = A/B selector of experimental instances of variant 3
- * (profiles/ experiment logs).  Results never depend on them; only speed does. */
+ * 16x16x32 shape (d padding to 384 .. 768, k <= 5)).  Results never depend on these four; only speed does.
+ * Two more names exist for tests and experiments and are NOT tuning knobs:
+ *   "spin_limit"  polls a wave spends on the scan's block barrier before it gives up (0 = the shipped 2^22).  A tiny
+ *                 value makes the kernel give up spuriously -- that is its purpose: tests use it to drive the
+ *                 MIPS_E_SCAN_TIMEOUT / MIPS_IDX_POISON path.  Never set it in production.
+ *   "sub"         A/B selector of experimental kernel instances (profiles/ experiment logs), two of which skip the
+ *                 top-k epilogue and return wrong results by design.  The shipped library does not contain them:
+ *                 any value but 0 returns MIPS_E_UNSUPPORTED unless the library was built with -DMIPS_EXPERIMENTAL
+ *                 (tools/ab.py does that into tools/_build/). */
 int mips_index_set_param(mips_index_t* index, const char* name, int64_t value);
+
+/* Scan-error check.  The fused scan kernels synchronise their waves per document block through a bounded poll; a
+ * wave that gives up sets an error word, the exact re-score of the same call then writes MIPS_IDX_POISON / NaN into
+ * every output slot and raises a sticky host-visible flag on the index.  This call reports (MIPS_E_SCAN_TIMEOUT) and
+ * clears that flag; with synchronize != 0 it first waits for `hip_stream`, so that every search enqueued there so
+ * far is covered.  mips_search itself performs the same check on entry (for the searches before it) and, when it
+ * writes to HOST buffers, after its own synchronisation.  Nothing in the reference corresponds (faiss IndexFlat
+ * cannot fail this way). */
+int mips_index_check_error(mips_index_t* index, int synchronize, void* hip_stream);
+
+/* Name of the scan-kernel instance the last mips_search on this index dispatched to, in the form rocprofv3 prints
+ * it (e.g. "mips::scan_kernel_v4<6, 24, 2, 0>"); "" before the first search.  bench.py's roofline.kernel. */
+const char* mips_index_last_kernel(const mips_index_t* index);
 
 /* Timing hook used by bench.py.  reset != 0 opens a measurement window: from then on every
  * mips_search records a HIP event pair around its fused scan kernel on the search stream (at most

@@ -27,6 +27,7 @@ Q_DEVICE, OUT_DEVICE, OUT_PACKED, FORCE_IP = 1, 2, 4, 8
 SYNTH_LATTICE, SYNTH_GAUSS, SYNTH_LATTICE_FP8 = 0, 1, 2
 SEED_DOCS, SEED_QUERIES = 0xD0C5, 0x0E21  # fixed seeds of the synthetic workloads
 MAX_K = 29
+IDX_POISON = -2  # MIPS_IDX_POISON: what a search whose scan kernel timed out returns in every slot
 
 _lock = threading.Lock()
 _lib = None
@@ -45,6 +46,27 @@ def _stale() -> bool:
         return True
     t = os.path.getmtime(LIB_PATH)
     return any(os.path.getmtime(s) > t for s in _sources())
+
+
+EXP_LIB_PATH = os.path.join(_ROOT, "tools", "_build", "libmips_hip_exp.so")
+
+
+def build_experimental(verbose: bool = False) -> str:
+    """The A/B build for tools/ab.py: the same source with -DMIPS_EXPERIMENTAL (the `sub` instances of the
+    experiment logs under profiles/, two of which return wrong results by design).  Never loaded by the product
+    unless MIPS_HIP_EXPERIMENTAL=1 is set in the environment."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(os.path.dirname(EXP_LIB_PATH), exist_ok=True)
+    if os.path.exists(EXP_LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(EXP_LIB_PATH) for s in _sources()):
+        return EXP_LIB_PATH
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DMIPS_EXPERIMENTAL",
+           "-o", EXP_LIB_PATH, os.path.join(CSRC, "mips_hip.hip")]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
+    return EXP_LIB_PATH
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -106,6 +128,8 @@ def _bind(lib):
         "mips_rows_max_sumsq": (i32, [vp, i64, i64, c.POINTER(c.c_double), i32, vp]),
         "mips_index_set_param": (i32, [vp, c.c_char_p, i64]),
         "mips_scan_timing": (i32, [vp, c.POINTER(c.c_float), c.POINTER(c.c_int), i32]),
+        "mips_index_check_error": (i32, [vp, i32, vp]),
+        "mips_index_last_kernel": (c.c_char_p, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
@@ -120,6 +144,7 @@ EXPORTS = (
     "mips_index_dim", "mips_index_metric", "mips_index_phi", "mips_index_set_phi", "mips_index_read_rows",
     "mips_index_add_synthetic", "mips_synth_fill", "mips_search", "mips_merge_topk",
     "mips_merge_topk_packed", "mips_filter_ignore", "mips_cosine_rescore", "mips_cosine_rescore_bias", "mips_l2_normalize", "mips_rows_max_sumsq", "mips_index_set_param", "mips_scan_timing",
+    "mips_index_check_error", "mips_index_last_kernel",
 )
 
 
@@ -134,7 +159,7 @@ def load():
             return _lib
         import torch  # noqa: F401  (must precede dlopen, see docstring)
 
-        path = build()
+        path = build_experimental() if os.environ.get("MIPS_HIP_EXPERIMENTAL") == "1" else build()
         lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
         _bind(lib)
         ver = lib.mips_abi_version()

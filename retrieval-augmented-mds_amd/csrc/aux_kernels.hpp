@@ -361,7 +361,15 @@ struct MergeArgs {
     float* out_s; // [nq][k]
     int64_t* out_i;
     int64_t* out_packed; // optional [nq][k][2] = {float bits (zero-extended), global id}: the all-gather payload
+    const unsigned* err; // the scan kernel's error word of this call (nullptr: the generic kernel has no bounded spin)
+    unsigned* sticky;    // host-visible (pinned, mapped) word of the index: set to 1 when `err` was set
 };
+
+// What a search whose scan kernel gave up (split-barrier spin bound, scan_kernel_v3.hpp) returns instead of
+// results: every slot idx = IDX_POISON, score = NaN.  The cross-shard merges propagate it, so a timed-out shard
+// can never silently drop out of a global top-k (include/mips_hip.h, MIPS_IDX_POISON).
+constexpr int64_t IDX_POISON = -2;
+__device__ __forceinline__ float poison_score() { return __uint_as_float(0x7fc00000u); }
 
 // Split merge + exact re-score, two launches:
 //
@@ -431,6 +439,20 @@ __global__ __launch_bounds__(64) void rescore_rank_kernel(MergeArgs p, const int
     const int64_t q = (int64_t)blockIdx.x * QPW + lane / KL;
     const int slot = lane % KL;
     const bool inq = q < nq && lane < QPW * KL; // K' = 10: lanes 60..63 belong to no query
+    if (p.err != nullptr && *p.err != 0u) { // the scan gave up on its barrier: nothing below can be trusted
+        if (blockIdx.x == 0 && lane == 0) __hip_atomic_store(p.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (inq && slot < p.k) {
+            const size_t o = (size_t)q * p.k + slot;
+            if (p.out_packed) {
+                p.out_packed[2 * o] = (int64_t)__float_as_uint(poison_score());
+                p.out_packed[2 * o + 1] = IDX_POISON;
+            } else {
+                p.out_s[o] = poison_score();
+                p.out_i[o] = IDX_POISON;
+            }
+        }
+        return;
+    }
     const int ci = inq ? cand[(size_t)q * KL + slot] : IDX_NONE;
     const bool valid = ci != IDX_NONE;
     double dot = 0.0, qq = 0.0;
@@ -518,6 +540,15 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const float* cand_s, con
     const int q = blockIdx.x;
     const float* s = cand_s + (size_t)q * c;
     const int64_t* id = cand_i + (size_t)q * c;
+    bool bad = false; // a shard handed over poisoned results: the merged row is poisoned too
+    for (int a = threadIdx.x; a < c; a += 64) bad |= id[a] == IDX_POISON;
+    if (__ballot(bad) != 0ull) {
+        for (int t = threadIdx.x; t < k; t += 64) {
+            out_s[(size_t)q * k + t] = poison_score();
+            out_i[(size_t)q * k + t] = IDX_POISON;
+        }
+        return;
+    }
     for (int a = threadIdx.x; a < c; a += 64) {
         const float sa = metric == 1 ? -s[a] : s[a];
         const int64_t ia = id[a] < 0 ? INT64_MAX : id[a];
@@ -545,6 +576,15 @@ __global__ __launch_bounds__(64) void merge_topk_packed_kernel(const int64_t* ga
         return metric == 1 ? -f : f;
     };
     auto ident = [&](int a) { return gathered[(((size_t)(a / k) * nq + q) * k + a % k) * 2 + 1]; };
+    bool bad = false;
+    for (int a = threadIdx.x; a < c; a += 64) bad |= ident(a) == IDX_POISON;
+    if (__ballot(bad) != 0ull) {
+        for (int t = threadIdx.x; t < k; t += 64) {
+            out_s[(size_t)q * k + t] = poison_score();
+            out_i[(size_t)q * k + t] = IDX_POISON;
+        }
+        return;
+    }
     for (int a = threadIdx.x; a < c; a += 64) {
         const float sa = score(a);
         const int64_t raw = ident(a);

@@ -114,6 +114,12 @@ struct mips_index {
     int opt_qgroups = 0;
     size_t err_off = 0; // word offset of the scan kernel's error flag inside gthr (0 = none this call)
     int opt_sub = 0;
+    int opt_spin_limit = 0; // test-only: polls of the split barrier before a wave gives up (0 = 1 << 22)
+    // sticky scan-error flag: one pinned, mapped host word.  The exact re-score sets it (system-scope store) when
+    // the scan kernel of its call gave up on the split barrier; the host reads it without a device round trip.
+    unsigned* sticky_host = nullptr;
+    unsigned* sticky_dev = nullptr;
+    char last_kernel[96] = ""; // instance mips_search dispatched last (mips_index_last_kernel)
     int opt_variant = 0; // 0 = automatic, 1 = scan_kernel (128x128 tiles), 3 = scan_kernel_v3 (32x32x16), 4 = scan_kernel_v4 (16x16x32)
     hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
     int ev_count = 0; // pairs recorded since the last reset (saturates at kEvRing)
@@ -149,6 +155,24 @@ struct StreamOrder {
 #define ORDER_ON(ix, st)             \
     StreamOrder order_guard(ix, st); \
     if (!order_guard.ok) return fail(MIPS_E_HIP, "hipStreamWaitEvent failed")
+
+// A scan kernel whose split barrier timed out poisons its call's output and raises the sticky flag; whoever looks
+// first (the next call on the index, mips_index_check_error, a host-output search) reports and clears it.
+int take_scan_error(mips_index* ix, const char* who) {
+    if (ix->sticky_host == nullptr) return MIPS_OK;
+    if (__atomic_load_n(ix->sticky_host, __ATOMIC_ACQUIRE) == 0u) return MIPS_OK;
+    __atomic_store_n(ix->sticky_host, 0u, __ATOMIC_RELEASE);
+    return fail(MIPS_E_SCAN_TIMEOUT,
+                "%s: a scan kernel on this index gave up on its block barrier (spin bound reached); the results of "
+                "that search were poisoned (idx %d, NaN scores) and must be discarded", who, MIPS_IDX_POISON);
+}
+
+void set_kernel_name(mips_index* ix, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ix->last_kernel, sizeof ix->last_kernel, fmt, ap);
+    va_end(ap);
+}
 
 // exact = false: geometric growth for repeated adds; true: mips_index_reserve's exact reservation
 int grow(mips_index* ix, int64_t need_rows, hipStream_t st, bool exact = false) {
@@ -350,7 +374,11 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // v4 keeps 4 sub-lists per (query, split); each needs k (<= 5) + 1 entries only, the re-score pool is
     // still the K' = 8 best of their union
     constexpr int V4_KLL = 6;
+#ifdef MIPS_EXPERIMENTAL
     const bool short_lists = !want_v4 && KL == 8 && variant == 3 && !f8 && ix->ld == 768 && (ix->opt_sub == 10 || ix->opt_sub == 11);
+#else
+    const bool short_lists = false;
+#endif
     const size_t ncand = (size_t)nsplit * lists * ((want_v4 || want_f8x || short_lists) ? V4_KLL : KL);
     int rc = ix->part_s.ensure((size_t)nq_pad * ncand * sizeof(float));
     if (rc) return rc;
@@ -375,6 +403,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     a.part_i = (int*)ix->part_i.p;
     a.gthr = nullptr;
     a.err = nullptr;
+    a.spin_limit = ix->opt_spin_limit > 0 ? ix->opt_spin_limit : (1 << 22);
     ix->err_off = 0;
     if (variant == 3) {
         // shared insert bounds: 8 class words per query (2 lane-half words in the older layouts) + error word
@@ -397,12 +426,16 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
                 return MIPS_OK;
             };
             int rc2;
+#ifdef MIPS_EXPERIMENTAL
             if (ix->ld == 768 && ix->opt_sub == 8) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 1>); // timing only: no epilogue
-            else if (ix->ld == 768) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2>);
+            else
+#endif
+            if (ix->ld == 768) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2>);
             else if (ix->ld == 640) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 20, 2>);
             else if (ix->ld == 512) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 16, 2>);
             else rc2 = go4(mips::scan_kernel_v4<V4_KLL, 12, 2>);
             if (rc2) return rc2;
+            set_kernel_name(ix, "mips::scan_kernel_v4<%d, %d, 2, 0>", V4_KLL, ix->ld / 32);
         }
     } else if (want_f8x) {
         if constexpr (KL == 8) {
@@ -418,11 +451,15 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
                 return MIPS_OK;
             };
             int rc2;
+#ifdef MIPS_EXPERIMENTAL
             if (ix->ld == 768 && ix->opt_sub == 8) rc2 = gox(mips::scan_kernel_f8x<V4_KLL, 768, 2, 1>); // timing only: no epilogue
-            else if (ix->ld == 768) rc2 = gox(mips::scan_kernel_f8x<V4_KLL, 768, 2>);
+            else
+#endif
+            if (ix->ld == 768) rc2 = gox(mips::scan_kernel_f8x<V4_KLL, 768, 2>);
             else if (ix->ld == 512) rc2 = gox(mips::scan_kernel_f8x<V4_KLL, 512, 2>);
             else rc2 = gox(mips::scan_kernel_f8x<V4_KLL, 256, 2>);
             if (rc2) return rc2;
+            set_kernel_name(ix, "mips::scan_kernel_f8x<%d, %d, 2, 0>", V4_KLL, ix->ld);
         }
     } else if (f8) {
         if constexpr (KL <= 16) {
@@ -443,12 +480,14 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             else if (ix->ld == 512) rc2 = gof8(mips::scan_kernel_f8<KL, 512, 2>);
             else rc2 = gof8(mips::scan_kernel_f8<KL, 256, 2>);
             if (rc2) return rc2;
+            set_kernel_name(ix, "mips::scan_kernel_f8<%d, %d, 2>", KL, ix->ld);
         }
     } else if (variant == 1) {
         HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel<KL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     mips::SCAN_LDS_BYTES));
         if (ix->timing_armed) HIP_TRY(hipEventRecord(ix->ev0[slot], st));
         mips::scan_kernel<KL><<<grid, mips::SCAN_THREADS, mips::SCAN_LDS_BYTES, st>>>(a);
+        set_kernel_name(ix, "mips::scan_kernel<%d>", KL);
     } else if constexpr (!kl_short) {
         // 4-wave configuration, 3-stage ring (d <= 768: 3 x 48 KiB)
         const int lds = 3 * mips::V3_DB * ix->ld * 2 + 4 * 1024 + 1024 + 16;
@@ -463,25 +502,26 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         else if (ix->ld == 512) rc2 = go4(mips::scan_kernel_v3<KL, 32, 1, 4, true, 0, 2, 4, 3>);
         else rc2 = go4(mips::scan_kernel_v3<KL, 16, 1, 4, true, 0, 2, 4, 3>);
         if (rc2) return rc2;
+        set_kernel_name(ix, "mips::scan_kernel_v3<%d, %d, 1, 4, true, 0, 2, 4, 3, true, false, 8>", KL, ix->ld / 16);
     } else {
         const int lds = (v3_waves == 4 ? 2 : 3) * mips::V3_DB * ix->ld * 2 + v3_waves * 1024 + 1024 + 16; // ring + threshold words + dump area + arrival counter
-        const int sub = KL == 8 ? ix->opt_sub : 0; // A/B selector for tools/ab.py (0 = shipped configuration)
         auto go = [&](auto kern, int threads) -> int {
             HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             if (ix->timing_armed) HIP_TRY(hipEventRecord(ix->ev0[slot], st));
             kern<<<grid, threads, lds, st>>>(a);
             return MIPS_OK;
         };
-        int rc2;
-        if (ix->ld == 1024) rc2 = go(mips::scan_kernel_v3<KL, 64, 1, 4, false, 0, 2, 4, 2>, 256);
-        else if (ix->ld == 640) rc2 = go(mips::scan_kernel_v3<KL, 40, 1, 2, true>, 512);
-        else if (ix->ld == 512) rc2 = go(mips::scan_kernel_v3<KL, 32, 1, 2, true>, 512);
-        else if (ix->ld == 384) rc2 = go(mips::scan_kernel_v3<KL, 24, 1, 2, true>, 512);
-        else if (ix->ld == 256) rc2 = go(mips::scan_kernel_v3<KL, 16, 1, 2, true>, 512);
-        else if (ix->ld == 128) rc2 = go(mips::scan_kernel_v3<KL, 8, 1, 2, true>, 512);
-        else if (sub == 3) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, 2, 8, 3, false>, 512);  // hardware s_barrier per block
+        int rc2 = MIPS_OK;
+        bool launched = false;
+        set_kernel_name(ix, "mips::scan_kernel_v3<%d, %d, 1, 2, true, 0, 2, 8, 3, true, false, 8>", KL, ix->ld / 16);
+#ifdef MIPS_EXPERIMENTAL
+        // A/B instances of the experiment logs under profiles/ (tools/ab.py builds the library with
+        // -DMIPS_EXPERIMENTAL; the shipped library does not contain them: sub 8 / 9 return wrong results by design)
+        const int sub = (KL == 8 && ix->ld == 768) ? ix->opt_sub : 0;
+        launched = sub != 0;
+        if (sub == 3) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, 2, 8, 3, false>, 512);  // hardware s_barrier per block
         else if (sub == 7) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, 2, 8, 3, true, true>, 512);  // nt document DMA
-        else if (sub == 6) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, 1, 8, 3, true, false, 1>, 512);  // shared K'-th bests, re-read every block (the round's earlier default)
+        else if (sub == 6) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, 1, 8, 3, true, false, 1>, 512);  // shared K'-th bests, re-read every block
         else if (sub == 15) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, 2, 8, 3, true, false, 1>, 512); // class maxima re-read every block
         else if (sub == 1) rc2 = go(mips::scan_kernel_v3<KL, 48, 2, 6, true, 0, 0, 4, 3, true>, 256);  // 4 waves x 64 queries
         else if (sub == 10) rc2 = go(mips::scan_kernel_v3<6, 48, 1, 2, true>, 512);             // 6-entry lists
@@ -491,9 +531,24 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         else if (sub == 5) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 3, true>, 512);             // prefetch depth 3
         else if (sub == 8) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 1>, 512);          // timing only: no epilogue
         else if (sub == 9) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 2>, 512);          // timing only: pre-test only
-        else if (nqt == 1) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, 2, 8, 3, true, true>, 512);  // one query tile:
-        // every document block has a single reader, so its DMA is non-temporal (HBM-bound regime: 5.5 -> 5.9 TB/s)
-        else rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true>, 512);
+        else launched = false;
+        if (launched) set_kernel_name(ix, "mips::scan_kernel_v3 experimental instance sub=%d", sub);
+#endif
+        if (launched) {
+        } else if (ix->ld == 1024) {
+            rc2 = go(mips::scan_kernel_v3<KL, 64, 1, 4, false, 0, 2, 4, 2>, 256);
+            set_kernel_name(ix, "mips::scan_kernel_v3<%d, 64, 1, 4, false, 0, 2, 4, 2, true, false, 8>", KL);
+        } else if (ix->ld == 768 && nqt == 1) {
+            // one query tile: every document block has a single reader, so its DMA is non-temporal (HBM-bound
+            // regime: 5.5 -> 5.9 TB/s)
+            rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, 2, 8, 3, true, true>, 512);
+            set_kernel_name(ix, "mips::scan_kernel_v3<%d, 48, 1, 2, true, 0, 2, 8, 3, true, true, 8>", KL);
+        } else if (ix->ld == 768) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true>, 512);
+        else if (ix->ld == 640) rc2 = go(mips::scan_kernel_v3<KL, 40, 1, 2, true>, 512);
+        else if (ix->ld == 512) rc2 = go(mips::scan_kernel_v3<KL, 32, 1, 2, true>, 512);
+        else if (ix->ld == 384) rc2 = go(mips::scan_kernel_v3<KL, 24, 1, 2, true>, 512);
+        else if (ix->ld == 256) rc2 = go(mips::scan_kernel_v3<KL, 16, 1, 2, true>, 512);
+        else rc2 = go(mips::scan_kernel_v3<KL, 8, 1, 2, true>, 512);
         if (rc2) return rc2;
     }
     HIP_TRY(hipGetLastError());
@@ -517,6 +572,8 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     m.out_s = d_out_s;
     m.out_i = d_out_i;
     m.out_packed = d_out_packed;
+    m.err = a.err;
+    m.sticky = ix->sticky_dev;
     // (1) K' best candidates per query by MFMA score, (2) lane-packed exact re-score + final order
     rc = ix->cand.ensure((size_t)nq * KL * sizeof(int));
     if (rc) return rc;
@@ -584,6 +641,13 @@ int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, 
         mips_index_destroy(ix);
         return fail(MIPS_E_HIP, "hipEventCreate failed");
     }
+    // the sticky scan-error word: pinned host memory the device writes to (coherent, mapped)
+    if (hipHostMalloc((void**)&ix->sticky_host, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&ix->sticky_dev, ix->sticky_host, 0) != hipSuccess) {
+        mips_index_destroy(ix);
+        return fail(MIPS_E_HIP, "hipHostMalloc for the scan-error word failed");
+    }
+    *ix->sticky_host = 0u;
     *out = ix;
     return MIPS_OK;
 }
@@ -609,6 +673,7 @@ int mips_index_destroy(mips_index_t* ix) {
         if (ix->ev1[e]) (void)hipEventDestroy(ix->ev1[e]);
     }
     if (ix->busy) (void)hipEventDestroy(ix->busy);
+    if (ix->sticky_host) (void)hipHostFree(ix->sticky_host);
     delete ix;
     return MIPS_OK;
 }
@@ -746,6 +811,11 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
     if (nq > (1 << 24)) return fail(MIPS_E_UNSUPPORTED, "mips_search: more than 2^24 queries in one call");
     DeviceGuard g(ix->device);
     hipStream_t st = (hipStream_t)hip_stream;
+    {   // an earlier device-output search on this index whose scan timed out: report it now (no synchronisation:
+        // the word lives in host memory), before anything new is enqueued
+        const int prev = take_scan_error(ix, "mips_search");
+        if (prev) return prev;
+    }
     ORDER_ON(ix, st);
     const bool out_dev = (flags & MIPS_OUT_DEVICE) != 0;
     const bool packed = (flags & MIPS_OUT_PACKED) != 0;
@@ -797,7 +867,13 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
                               (uint32_t*)ix->gthr.p, thr_words);
             if (rc) return rc;
         }
-        // K' = list length of the scan >= k + 3: the MFMA scores only SELECT candidates
+        // The MFMA scores only SELECT a pool of K' candidates that is then re-scored exactly.
+        // Pool K' = 8 / 10 / 16 / 32 >= k + 3.  What is GUARANTEED to reach the pool per (query, split): the 32x32
+        // kernels (scan_kernel_v3 / f8 / generic) keep lists of K' entries, so MFMA ranks 1 .. K'; the 16x16 kernels
+        // (scan_kernel_v4 / f8x: bf16 pitch 384 .. 768 or fp8 pitch <= 768, k <= 5, more than one query tile) keep 4
+        // sub-lists of 6, so MFMA ranks 1 .. 6 = k + 1 for certain and 7 .. 8 unless 6 better documents share the
+        // sub-list (rows congruent mod 16 within a split).  Queries whose k-th exact score is too close to what the
+        // pool may have lost are detected by the re-score and re-scanned with the widest lists (margin check below).
         if (k <= 5)
             rc = launch_search<8>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st);
         else if (k <= 7) // k + 1 = 6 is what Mips.search fetches for top_k = 5 with ignore_indexes (mips.py:388-398)
@@ -811,11 +887,10 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
     if (!out_dev) {
         HIP_TRY(hipMemcpyAsync(out_scores, d_s, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(out_idx, d_i, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-        unsigned err = 0;
-        const bool have_err = ix->ntotal > 0 && ix->gthr.p != nullptr && ix->err_off != 0;
-        if (have_err) HIP_TRY(hipMemcpyAsync(&err, (unsigned*)ix->gthr.p + ix->err_off, sizeof err, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (err) return fail(MIPS_E_HIP, "mips_search: scan kernel synchronisation timed out (results invalid)");
+        // host buffers: the stream is drained, so a timed-out scan of THIS call is known now
+        const int bad = take_scan_error(ix, "mips_search");
+        if (bad) return bad;
     }
     return MIPS_OK;
 }
@@ -906,8 +981,13 @@ int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out
     DeviceGuard g(device);
     if (!g.ok) return fail(MIPS_E_HIP, "hipSetDevice(%d) failed", device);
     hipStream_t st = (hipStream_t)hip_stream;
-    unsigned long long* slot = nullptr;
-    HIP_TRY(hipMalloc((void**)&slot, 8));
+    // one 8-byte result slot per (host thread, device), allocated once: the rebuild path calls this per build
+    // (mips.py:298-304), and a hipMalloc / hipFree pair per call serialises the device
+    constexpr int kMaxDev = 64;
+    thread_local unsigned long long* slots[kMaxDev] = {};
+    if (device < 0 || device >= kMaxDev) return fail(MIPS_E_INVALID, "mips_rows_max_sumsq: device %d out of range", device);
+    if (!slots[device]) HIP_TRY(hipMalloc((void**)&slots[device], 8));
+    unsigned long long* slot = slots[device];
     hipError_t e = hipMemsetAsync(slot, 0, 8, st);
     if (e == hipSuccess) {
         mips::f32_rows_max_sumsq_kernel<<<(int)std::min<int64_t>((n + 3) / 4, 256 * 16), 256, 0, st>>>(x_device, n, (int)d, slot);
@@ -916,7 +996,6 @@ int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out
     unsigned long long bits = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&bits, slot, 8, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(slot);
     if (e != hipSuccess) return fail(MIPS_E_HIP, "mips_rows_max_sumsq: %s", hipGetErrorString(e));
     std::memcpy(out_host, &bits, 8);
     return MIPS_OK;
@@ -928,10 +1007,29 @@ int mips_index_set_param(mips_index_t* ix, const char* name, int64_t value) {
     if (n == "nsplit") ix->opt_nsplit = (int)value;
     else if (n == "qgroups") ix->opt_qgroups = (int)value;
     else if (n == "variant") ix->opt_variant = (int)value;
-    else if (n == "sub") ix->opt_sub = (int)value;
-    else return fail(MIPS_E_INVALID, "mips_index_set_param: unknown parameter '%s'", name);
+    else if (n == "spin_limit") ix->opt_spin_limit = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
+    else if (n == "sub") {
+#ifdef MIPS_EXPERIMENTAL
+        ix->opt_sub = (int)value;
+#else
+        if (value != 0)
+            return fail(MIPS_E_UNSUPPORTED, "mips_index_set_param: 'sub' selects experimental kernel instances that the shipped "
+                                            "library does not contain (build with -DMIPS_EXPERIMENTAL, tools/ab.py)");
+#endif
+    } else return fail(MIPS_E_INVALID, "mips_index_set_param: unknown parameter '%s'", name);
     return MIPS_OK;
 }
+
+int mips_index_check_error(mips_index_t* ix, int synchronize, void* hip_stream) {
+    if (!ix) return fail(MIPS_E_INVALID, "mips_index_check_error: index is NULL");
+    if (synchronize) {
+        DeviceGuard g(ix->device);
+        HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+    }
+    return take_scan_error(ix, "mips_index_check_error");
+}
+
+const char* mips_index_last_kernel(const mips_index_t* ix) { return ix ? ix->last_kernel : ""; }
 
 int mips_scan_timing(mips_index_t* ix, float* out_sum_ms, int* out_count, int reset) {
     if (!ix) return fail(MIPS_E_INVALID, "mips_scan_timing: index is NULL");

@@ -57,7 +57,9 @@ struct ScanArgs {
     float* part_s;        // [nq_pad][nsplit][2][KL]
     int* part_i;
     unsigned* gthr;       // [2 nq_pad] shared per-query thresholds (order-preserving keys, 0 = none), v3 only
-    unsigned* err;        // one word, zeroed per launch: set when a bounded spin gave up (never expected)
+    unsigned* err;        // one word, zeroed per launch: set when a bounded spin gave up (never expected).  The exact
+                          // re-score reads it and POISONS the call's output (idx -2, NaN) -- aux_kernels.hpp
+    int spin_limit;       // polls of the split barrier before a wave gives up (1 << 22; tests shrink it to force the flag)
     int plane;            // > 0: fp32-exact mode (generic kernel only).  Rows are two bf16 planes [hi | lo] of
                           // `plane` elements each (x = hi + lo up to 2^-17 relative) and the k-loop runs three
                           // segments hi.qhi + hi.qlo + lo.qhi; ld = 2 * plane, ksteps = 3 * plane / BK.

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_f8x(ScanArgsF8 pa) {
             asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(cnt_lds) : "memory");
 #endif
             if (__builtin_amdgcn_readfirstlane(v) >= arrivals_needed) break;
-            if (spin > (1 << 22)) {
+            if (spin > p.spin_limit) {
                 if (lane == 0) *p.err = 1u;
                 break;
             }

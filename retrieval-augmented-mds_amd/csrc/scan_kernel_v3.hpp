@@ -246,7 +246,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
             asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(cnt_lds) : "memory");
 #endif
             if (__builtin_amdgcn_readfirstlane(v) >= arrivals_needed) break;
-            if (spin > (1 << 22)) {
+            if (spin > p.spin_limit) {
                 if (lane == 0) *p.err = 1u;
                 break;
             }

@@ -209,8 +209,23 @@ class MipsIndex:
         return out
 
     def set_param(self, name: str, value: int) -> None:
-        """Launch tuning knob ("nsplit", "qgroups"); never changes results."""
+        """Launch tuning knob ("nsplit", "qgroups", "variant"); never changes results.  ("spin_limit" is the
+        test-only bound of the scan's block barrier, include/mips_hip.h.)"""
         _lib.check(self._lib.mips_index_set_param(self._h, name.encode(), int(value)), "mips_index_set_param")
+
+    def check(self, synchronize: bool = True) -> None:
+        """Raise RuntimeError if a scan kernel of an earlier search on this index gave up on its block barrier
+        (that search returned idx = IDX_POISON / NaN in every slot).  synchronize=True first waits for the
+        current stream, so every search enqueued so far is covered; False only looks at the host-visible flag.
+        Device-output searches never synchronise by themselves: call this where a sync is affordable (end of a
+        batch, before results leave the process).  The next search on the index performs the same check."""
+        _lib.check(self._lib.mips_index_check_error(self._h, int(bool(synchronize)), _stream_handle(self.device)),
+                   "mips_index_check_error")
+
+    @property
+    def last_kernel(self) -> str:
+        """Scan-kernel instance the last search dispatched to (rocprofv3 spelling)."""
+        return self._lib.mips_index_last_kernel(self._h).decode()
 
     def scan_timing(self, reset: bool = False):
         """(summed ms, launches) of the fused scan kernel in the current measurement window, from HIP events

@@ -114,12 +114,19 @@ class ShardedMipsIndex:
     def ntotal(self) -> int:
         return self.ntotal_global
 
+    def check(self, synchronize: bool = True) -> None:
+        """MipsIndex.check for this rank's shard.  A shard whose scan timed out hands poisoned rows (idx -2, NaN)
+        to the all-gather and the merge kernel propagates them, so every rank SEES the failure in its results;
+        the rank it happened on also raises here (and on its next search)."""
+        if self.local is not None:
+            self.local.check(synchronize)
+
     # ------------------------------------------------------------------ pipelined search
     class _Pending:
         """Result of search_async: .result() makes the CURRENT stream wait for the merged top-k and returns it."""
 
-        def __init__(self, out, done_event, keep):
-            self._out, self._done, self._keep = out, done_event, keep
+        def __init__(self, out, done_event, keep, index=None):
+            self._out, self._done, self._keep, self._index = out, done_event, keep, index
 
         def result(self):
             import torch
@@ -130,6 +137,8 @@ class ShardedMipsIndex:
                 for t in self._out:
                     t.record_stream(cur)  # allocated on the side stream, consumed on this one
                 self._done, self._keep = None, None
+            if self._index is not None:
+                self._index.check(synchronize=False)  # host-visible flag only: no synchronisation on this path
             return self._out
 
     def search_async(self, q, k: int, _force_collective: bool = False):
@@ -165,7 +174,7 @@ class ShardedMipsIndex:
             out = merge_topk_packed(gathered, nq, self.world, k, self.metric_type)
             done = torch.cuda.Event()
             done.record(side)
-        return ShardedMipsIndex._Pending(out, done, (packed, gathered))
+        return ShardedMipsIndex._Pending(out, done, (packed, gathered), self.local)
 
     # ------------------------------------------------------------------ search
     def search(self, q, k: int):

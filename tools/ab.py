@@ -1,6 +1,7 @@
 """A/B harness (GPU box): times scan-kernel launch variants interleaved in ONE process.
 usage: python tools/ab.py "qgroups=1" "qgroups=4" "qgroups=4,nsplit=32" ... [--rows N --queries Q --rounds R]"""
 import argparse, sys, os
+os.environ["MIPS_HIP_EXPERIMENTAL"] = "1"  # the library build that contains the `sub` instances (tools/_build/)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import retrieval_augmented_mds_amd as ram

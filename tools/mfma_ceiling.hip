@@ -137,6 +137,120 @@ __global__ __launch_bounds__(512, 2) void mfma_loop16(const uint16_t* src, float
     if (t == 12345.678f) sink[0] = t;
 }
 
+
+// ---- Round 2: what would a mapping with FEWER LDS bytes per MFMA sustain?  mfma_loop16q: one A fragment (16
+// documents x 32 k) feeds NQB MFMAs (NQB 16-query column blocks per wave), the wave's stationary B fragments are
+// the REAL count (NQB x KS x 4 registers, half of them pinned in AGPRs when they exceed 200), the A operand comes
+// from a 48-KiB LDS block image as in scan_kernel_v4.  Shapes:
+//   NQB 2, KS 24, 8 waves (2 per SIMD)  = scan_kernel_v4's loop (1 read per 2 MFMAs, 192 fragment registers)
+//   NQB 4, KS 24, 4 waves (1 per SIMD)  = 64 stationary queries per wave (1 read per 4 MFMAs, 384 registers)
+//   NQB 4, KS 12, 8 waves (2 per SIMD)  = a wave PAIR splits K: each wave holds 64 queries x half of K (192
+//                                          registers) and reads only its K half of the block (1 read per 4 MFMAs);
+//                                          the partial sums would still have to be exchanged (not modelled here)
+// The kernel also reports the clock it ran at (s_memtime / s_memrealtime around the loop, block 0).
+template <int NQB, int KS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void mfma_loop16q(const uint16_t* src, float* sink, int iters, unsigned long long* stamps) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[48 * 1024];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    bf16x8 b[NQB][KS];
+    const uint16_t* base = src + ((size_t)blockIdx.x * 512 + (threadIdx.x & 511)) * 8;
+#pragma unroll
+    for (int n = 0; n < NQB; ++n)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            b[n][s] = *reinterpret_cast<const bf16x8*>(base + (size_t)((n * KS + s) % NFRAG) * 512 * 8 * gridDim.x);
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (NQB * KS * 4 > 200 && (n * KS + s) >= NQB * KS / 2) asm volatile("" : "+a"(b[n][s]));
+            else asm volatile("" : "+v"(b[n][s]));
+#endif
+        }
+    for (int o = threadIdx.x * 16; o < 48 * 1024; o += WAVES * 64 * 16)
+        *reinterpret_cast<bf16x8*>(lds + o) = *reinterpret_cast<const bf16x8*>(src + (o / 2) % 4096 + (size_t)blockIdx.x * 4096);
+    __syncthreads();
+    f32x4 acc[NQB];
+#pragma unroll
+    for (int n = 0; n < NQB; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int c = lane & 15, g = lane >> 4, swz = (c >> 1) & 7;
+    const int rd0 = c * 128 + ((g ^ swz) << 4);
+    const int koff = KS == 12 ? (wave & 1) * 12 : 0; // K-split pair: odd waves read the second half of K
+    unsigned long long t0 = 0, r0 = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
+#endif
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            bf16x8 ar[2];
+            auto frag = [&](int s) {
+                const int ss = s + koff;
+                return *reinterpret_cast<const bf16x8*>(lds + half * 2048 + (ss >> 1) * 4096 + ((ss & 1) ? (rd0 ^ 64) : rd0));
+            };
+            ar[0] = frag(0);
+            ar[1] = frag(1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int n = 0; n < NQB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[s & 1], b[n][s], acc[n], 0, 0, 0);
+                if (s + 2 < KS) ar[s & 1] = frag(s + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if ((it & 63) == 63) {
+#pragma unroll
+            for (int n = 0; n < NQB; ++n) acc[n] *= 1e-6f;
+        }
+    }
+    unsigned long long t1 = 0, r1 = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+#endif
+    if (stamps && threadIdx.x == 0) {
+        stamps[2 * blockIdx.x] = t1 - t0;
+        stamps[2 * blockIdx.x + 1] = r1 - r0;
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int n = 0; n < NQB; ++n) t += acc[n][0] + acc[n][1] + acc[n][2] + acc[n][3];
+    if (t == 12345.678f) sink[0] = t;
+}
+
+typedef void (*kernq_t)(const uint16_t*, float*, int, unsigned long long*);
+static void runq(kernq_t kern, int threads, double flops_per_wg_iter, const char* name, const uint16_t* d_src, float* d_sink, int grid,
+                 double seconds, unsigned long long* d_stamps) {
+    const int iters = 4096;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int w = 0; w < 3; ++w) kern<<<grid, threads>>>(d_src, d_sink, iters, d_stamps);
+    CHECK(hipDeviceSynchronize());
+    double best = 0, last = 0, total_ms = 0;
+    int launches = 0;
+    while (total_ms < seconds * 1e3) {
+        CHECK(hipEventRecord(e0));
+        for (int r = 0; r < 8; ++r) kern<<<grid, threads>>>(d_src, d_sink, iters, d_stamps);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        total_ms += ms;
+        launches += 8;
+        last = 8.0 * grid * iters * flops_per_wg_iter / (ms * 1e-3) / 1e12;
+        if (last > best) best = last;
+    }
+    static unsigned long long h[2 * 1024];
+    CHECK(hipMemcpy(h, d_stamps, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost));
+    double ghz[1024];
+    for (int i = 0; i < grid; ++i) ghz[i] = h[2 * i + 1] ? (double)h[2 * i] / (double)h[2 * i + 1] * 0.1 : 0.0;
+    for (int i = 1; i < grid; ++i) // insertion sort: median over workgroups
+        for (int j = i; j > 0 && ghz[j] < ghz[j - 1]; --j) { double t = ghz[j]; ghz[j] = ghz[j - 1]; ghz[j - 1] = t; }
+    const double cyc_per_mfma = (double)h[0] / ((double)iters * flops_per_wg_iter / (threads / 64) / 16384.0);
+    printf("{\"case\": \"%s\", \"tflops_last\": %.1f, \"tflops_best\": %.1f, \"launches\": %d, \"workgroups\": %d, \"clock_ghz_median\": %.3f, \"cycles_per_mfma_wave0\": %.2f}\n",
+           name, last, best, launches, grid, ghz[grid / 2], cyc_per_mfma);
+    fflush(stdout);
+}
+
 // ---- fp8 (e4m3) on the block-scaled f8f6f4 instructions with unit scales, same structure: 32x32x64 (one 32-byte
 // A fragment per MFMA, two ds_read_b128) against 16x16x128 (one 32-byte A fragment per TWO MFMAs).
 typedef int v8i32 __attribute__((ext_vector_type(8)));
@@ -259,6 +373,22 @@ int main() {
     printf("{\"device\": \"%s\", \"compute_units\": %d}\n", prop.name, grid);
     const double f32 = MFMA_PER_IT * 32768.0;      // 48 MFMAs of 32x32x16
     const double f16 = 2 * 24 * 2 * 16384.0;       // two halves x 24 steps x 2 MFMAs of 16x16x32 (same flops)
+    if (getenv("MFMA_CEILING_ROUND2")) { // the round-2 mapping study only
+        unsigned long long* d_stamps;
+        CHECK(hipMalloc(&d_stamps, sizeof(unsigned long long) * 2 * 1024));
+        CHECK(hipMemset(d_stamps, 0, sizeof(unsigned long long) * 2 * 1024));
+        const double mf = 16384.0;
+        for (int rep = 0; rep < 2; ++rep) {
+            runq(mfma_loop16q<2, 24, 8>, 512, 8 * 2 * 24 * 2 * mf, "16x16x32 LDS-fed, 2 query blocks/wave (v4 loop), 8 waves, random", d_rand, d_sink, grid, 2.0, d_stamps);
+            runq(mfma_loop16q<4, 24, 4>, 256, 4 * 2 * 24 * 4 * mf, "16x16x32 LDS-fed, 4 query blocks/wave, 4 waves (1/SIMD), random", d_rand, d_sink, grid, 2.0, d_stamps);
+            runq(mfma_loop16q<4, 12, 8>, 512, 8 * 2 * 12 * 4 * mf, "16x16x32 LDS-fed, 4 query blocks/wave x half K (wave-pair K split), 8 waves, random", d_rand, d_sink, grid, 2.0, d_stamps);
+        }
+        runq(mfma_loop16q<2, 24, 8>, 512, 8 * 2 * 24 * 2 * mf, "16x16x32 LDS-fed, 2 query blocks/wave (v4 loop), 8 waves, zeros", d_zero, d_sink, grid, 2.0, d_stamps);
+        runq(mfma_loop16q<4, 24, 4>, 256, 4 * 2 * 24 * 4 * mf, "16x16x32 LDS-fed, 4 query blocks/wave, 4 waves (1/SIMD), zeros", d_zero, d_sink, grid, 2.0, d_stamps);
+        runq(mfma_loop16q<4, 12, 8>, 512, 8 * 2 * 12 * 4 * mf, "16x16x32 LDS-fed, wave-pair K split, 8 waves, zeros", d_zero, d_sink, grid, 2.0, d_stamps);
+        run(mfma_loop16<0>, f16, "16x16x32, registers, random N(0,1) bf16", d_rand, d_sink, grid, 2.0);
+        return 0;
+    }
     run(mfma_loop<0>, f32, "32x32x16, registers, zeros", d_zero, d_sink, grid, 2.0);
     run(mfma_loop<0>, f32, "32x32x16, registers, random N(0,1) bf16", d_rand, d_sink, grid, 2.0);
     run(mfma_loop<1>, f32, "32x32x16, A from LDS (ds_read_b128 per MFMA), zeros", d_zero, d_sink, grid, 2.0);
