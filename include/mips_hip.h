@@ -123,7 +123,9 @@ int mips_index_phi(mips_index_t* index, double* out_phi, void* hip_stream);
 
 /* Override phi (>= 0).  A row-sharded index needs ONE phi for all shards -- the maximum of the shards'
  * local values -- or L2 distances from different shards are not comparable.  Stays in force until
- * mips_index_reset; the caller re-establishes it after adding rows. */
+ * mips_index_reset or until it is dropped by passing a NEGATIVE phi (the next mips_index_phi then recomputes this
+ * shard's own maximum): rows added under an override do not change it, so after adding rows the caller drops it,
+ * re-reads the local values, reduces them over the shards and sets the result again. */
 int mips_index_set_phi(mips_index_t* index, double phi);
 
 /* Copy stored rows [row0, row0+n) in the index dtype ([n, d]: uint16 bf16 bits, uint8 e4m3 codes or float32) to HOST memory.
@@ -185,6 +187,16 @@ int mips_cosine_rescore_bias(const void* query, const void* cls, int dtype, int6
                              float* out, int64_t memory_seq_len, float* memory_bias, int device,
                              void* hip_stream);
 
+/* Backward of the two functions above.  In the reference only the norms sit under torch.no_grad()
+ * (retriever_generator.py:160-171): `query @ mips_cls.transpose(1, 2)` stays in the autograd graph, and memory_bias
+ * is the path through which the query and memory encoders receive their retrieval gradient.  With
+ * g[b][j] = grad_scores[b][j] + sum_t grad_memory_bias[b][j * memory_seq_len + t] (either pointer may be NULL) and
+ * w = g / (|q| |c|), norms treated as constants:  grad_query[b] = sum_j w[b][j] c_bj,  grad_cls[b][j] = w[b][j] q_b.
+ * All DEVICE buffers; grads float32 ([b, d] and [b, k, d]); k <= 64. */
+int mips_cosine_rescore_backward(const void* query, const void* cls, int dtype, int64_t b, int k, int64_t d,
+                                 const float* grad_scores, const float* grad_memory_bias, int64_t memory_seq_len,
+                                 float* grad_query, float* grad_cls, int device, void* hip_stream);
+
 /* In-place row L2 normalisation of a DEVICE float32 matrix [n, d].  Replaces
  * faiss.normalize_L2 behind Mips.l2_normalization (sotasum/mips.py:521-525), used for documents
  * at build time (mips.py:306-314, 358-361) and for queries (mips.py:369-370).  Rows of norm 0 are
@@ -202,8 +214,9 @@ int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out
  * 16x16x32 shape (d padding to 384 .. 768, k <= 5)).  Results never depend on these four; only speed does.
  * Two more names exist for tests and experiments and are NOT tuning knobs:
  *   "spin_limit"  polls a wave spends on the scan's block barrier before it gives up (0 = the shipped 2^22).  A tiny
- *                 value makes the kernel give up spuriously -- that is its purpose: tests use it to drive the
- *                 MIPS_E_SCAN_TIMEOUT / MIPS_IDX_POISON path.  Never set it in production.
+ *                 value makes the kernel give up spuriously and -1 makes every scan launch raise its error word
+ *                 unconditionally -- that is their purpose: tests use them to drive the MIPS_E_SCAN_TIMEOUT /
+ *                 MIPS_IDX_POISON path.  Never set it in production.
  *   "sub"         A/B selector of experimental kernel instances (profiles/ experiment logs), two of which skip the
  *                 top-k epilogue and return wrong results by design.  The shipped library does not contain them:
  *                 any value but 0 returns MIPS_E_UNSUPPORTED unless the library was built with -DMIPS_EXPERIMENTAL

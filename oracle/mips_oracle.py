@@ -366,3 +366,45 @@ def memory_bias(mips_scores, memory_seq_len: int):
     [B,k] -> [B, k * memory_seq_len]."""
     b = mips_scores.shape[0]
     return mips_scores.unsqueeze(-1).expand(-1, -1, memory_seq_len).reshape(b, -1)
+
+
+# --------------------------------------------------------------------------
+# full-KB eval consumer      sotasum/retriever_lightning.py:312-321, 339-404
+# --------------------------------------------------------------------------
+def nearest_examples_batch(index_search, columns: dict, queries: np.ndarray, k: int):
+    """`Dataset.get_nearest_examples_batch("mips_cls", queries, k)` as the reference calls it
+    (retriever_lightning.py:317-321): HF datasets' search.py runs `faiss_index.search(queries, k)`, drops
+    ids < 0 per query and returns (scores per query, rows per query as a dict of columns).
+    index_search(q, k) -> (scores [nq, k], ids [nq, k])."""
+    s, i = index_search(np.ascontiguousarray(queries, dtype=np.float32), k)
+    scores, examples = [], []
+    for row_s, row_i in zip(s, i):
+        keep = [int(t) for t in row_i if t >= 0]
+        scores.append(np.asarray(row_s[: len(keep)]))
+        examples.append({c: [v[t] for t in keep] for c, v in columns.items()})
+    return scores, examples
+
+
+def full_kb_eval_index(cls: np.ndarray, inner_product: bool):
+    """on_validation_start, retriever_lightning.py:372-404: unless `inner_product`, phi = max |x|^2 and the
+    `cls` column is replaced by augment_xb(cls, phi); metric = IP or L2.  Returns (column to index, metric)."""
+    if inner_product:
+        return cls, METRIC_INNER_PRODUCT
+    phi = max((cls ** 2).sum(1))
+    return augment_xb(cls, phi), METRIC_L2
+
+
+# --------------------------------------------------------------------------
+# in-batch scoring      sotasum/retriever_lightning.py:304-305 (predict), 273-277 (train accuracy)
+# --------------------------------------------------------------------------
+def in_batch_scores(query_cls, mips_cls, normalize: bool = False):
+    """`scores = query_cls @ mips_cls.T; _, i = scores.topk(1)` (:304-305); with normalize the
+    `F.normalize(query_cls) @ F.normalize(mips_cls).T` of :273-277.  torch tensors -> (scores [B,B], top1 [B])."""
+    import torch
+    import torch.nn.functional as F
+
+    if normalize:
+        query_cls, mips_cls = F.normalize(query_cls), F.normalize(mips_cls)
+    scores = query_cls @ mips_cls.T
+    _, i = scores.topk(1)
+    return scores, i.view(-1)

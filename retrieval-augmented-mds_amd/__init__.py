@@ -8,17 +8,17 @@ Everything numeric runs in libmips_hip.so (hand-written HIP for gfx950, csrc/); 
 fallback.  See DESIGN.md and include/mips_hip.h.
 """
 from . import _lib
-from ._lib import (DTYPE_BF16, DTYPE_F32, MAX_K, METRIC_IP, METRIC_L2, SEED_DOCS, SEED_QUERIES, SYNTH_GAUSS,
+from ._lib import (DTYPE_BF16, DTYPE_F32, IDX_POISON, MAX_K, METRIC_IP, METRIC_L2, SEED_DOCS, SEED_QUERIES, SYNTH_GAUSS,
                    SYNTH_LATTICE, SYNTH_LATTICE_FP8, build)
 from .index import (MipsIndex, cosine_rescore, filter_ignore, l2_normalize_, merge_topk, merge_topk_packed,
                     rows_max_sumsq, synth_fill)
 from .mips import (KnowledgeBase, Mips, MipsArgs, MipsModelOutput, augment_xb, augment_xq, get_phi,
-                   inner_product, retriever_metrics)
+                   in_batch_scores, inner_product, retriever_metrics)
 from .sharded import ShardedMipsIndex, pack_topk, shard_bounds, unpack_gathered
 
 __all__ = [
     "MipsIndex", "ShardedMipsIndex", "Mips", "MipsArgs", "MipsModelOutput", "KnowledgeBase",
-    "get_phi", "augment_xb", "augment_xq", "inner_product", "retriever_metrics",
+    "get_phi", "augment_xb", "augment_xq", "inner_product", "in_batch_scores", "retriever_metrics", "IDX_POISON",
     "l2_normalize_", "rows_max_sumsq", "merge_topk", "merge_topk_packed", "filter_ignore", "cosine_rescore", "synth_fill", "shard_bounds", "pack_topk",
     "unpack_gathered", "build", "METRIC_IP", "METRIC_L2", "MAX_K",
 ]

@@ -661,6 +661,59 @@ __global__ __launch_bounds__(256) void cosine_rescore_kernel(const T* query, con
         for (int64_t t = lane; t < mem_len; t += 64) bias[pr * mem_len + t] = cosv;
 }
 
+// Backward of the hook's re-score.  In the reference only the NORMS are under torch.no_grad()
+// (retriever_generator.py:160-171); `query @ mips_cls.transpose(1, 2)` stays in the autograd graph and is the path
+// through which the retriever's encoders get their gradient.  With w[b][j] = g[b][j] / (|q_b| |c_bj|), norms constant:
+//     dL/dq_b = sum_j w[b][j] c_bj          dL/dc_bj = w[b][j] q_b
+// g = grad of the scores + the sum over the memory tokens of the grad of memory_bias (an expand, :188-192).
+// One 256-thread workgroup per batch row b; k <= 64.
+template <typename T>
+__global__ __launch_bounds__(256) void cosine_rescore_bwd_kernel(const T* query, const T* cls, int k, int d, const float* g_scores,
+                                                                 const float* g_bias, int64_t mem_len, float* g_query, float* g_cls) {
+    __shared__ float w[64];
+    __shared__ float qq_s;
+    const int64_t b = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const T* q = query + b * d;
+    if (wave == 0) {
+        float qq = 0.f;
+        for (int t = lane; t < d; t += 64) {
+            const float a = load_as_f32<T>(q, t);
+            qq += a * a;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) qq += __shfl_xor(qq, off);
+        if (lane == 0) qq_s = qq;
+    }
+    __syncthreads();
+    for (int j = wave; j < k; j += 4) {
+        const T* c = cls + (b * k + j) * d;
+        float cc = 0.f, g = 0.f;
+        for (int t = lane; t < d; t += 64) {
+            const float v = load_as_f32<T>(c, t);
+            cc += v * v;
+        }
+        if (g_bias != nullptr)
+            for (int64_t t = lane; t < mem_len; t += 64) g += g_bias[(b * k + j) * mem_len + t];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            cc += __shfl_xor(cc, off);
+            g += __shfl_xor(g, off);
+        }
+        if (lane == 0) w[j] = ((g_scores ? g_scores[b * k + j] : 0.f) + g) / (sqrtf(qq_s) * sqrtf(cc));
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < d; t += 256) {
+        const float qv = load_as_f32<T>(q, t);
+        float gq = 0.f;
+        for (int j = 0; j < k; ++j) {
+            gq += w[j] * load_as_f32<T>(cls + (b * k + j) * d, t);
+            g_cls[(b * k + j) * d + t] = w[j] * qv;
+        }
+        g_query[b * d + t] = gq;
+    }
+}
+
 __global__ void fill_empty_kernel(float* out_s, int64_t* out_i, int64_t* out_packed, int64_t total, int metric) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t < total) {

@@ -114,7 +114,7 @@ struct mips_index {
     int opt_qgroups = 0;
     size_t err_off = 0; // word offset of the scan kernel's error flag inside gthr (0 = none this call)
     int opt_sub = 0;
-    int opt_spin_limit = 0; // test-only: polls of the split barrier before a wave gives up (0 = 1 << 22)
+    int opt_spin_limit = 0; // test-only: polls of the split barrier before a wave gives up (0 = 1 << 22, < 0 = flag forced)
     // sticky scan-error flag: one pinned, mapped host word.  The exact re-score sets it (system-scope store) when
     // the scan kernel of its call gave up on the split barrier; the host reads it without a device round trip.
     unsigned* sticky_host = nullptr;
@@ -403,7 +403,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     a.part_i = (int*)ix->part_i.p;
     a.gthr = nullptr;
     a.err = nullptr;
-    a.spin_limit = ix->opt_spin_limit > 0 ? ix->opt_spin_limit : (1 << 22);
+    a.spin_limit = ix->opt_spin_limit != 0 ? ix->opt_spin_limit : (1 << 22);
     ix->err_off = 0;
     if (variant == 3) {
         // shared insert bounds: 8 class words per query (2 lane-half words in the older layouts) + error word
@@ -729,7 +729,12 @@ int mips_index_phi(mips_index_t* ix, double* out_phi, void* hip_stream) {
 }
 
 int mips_index_set_phi(mips_index_t* ix, double phi) {
-    if (!ix || !(phi >= 0.0)) return fail(MIPS_E_INVALID, "mips_index_set_phi: bad argument");
+    if (!ix || phi != phi) return fail(MIPS_E_INVALID, "mips_index_set_phi: bad argument");
+    if (phi < 0.0) { // drop the override: the next mips_index_phi / L2 search recomputes the local maximum
+        ix->phi_override = false;
+        ix->phi_valid = false;
+        return MIPS_OK;
+    }
     ix->phi = phi;
     ix->phi_valid = true;
     ix->phi_override = true;
@@ -779,7 +784,7 @@ int mips_index_add_synthetic(mips_index_t* ix, int64_t n, int64_t row0, uint64_t
     }
     HIP_TRY(hipGetLastError());
     ix->ntotal += n;
-    ix->phi_valid = false;
+    if (!ix->phi_override) ix->phi_valid = false; // as mips_index_add: an override stays until the caller renews it
     return MIPS_OK;
 }
 
@@ -964,6 +969,26 @@ int mips_cosine_rescore_bias(const void* query, const void* cls, int dtype, int6
                                hip_stream);
 }
 
+int mips_cosine_rescore_backward(const void* query, const void* cls, int dtype, int64_t b, int k, int64_t d, const float* grad_scores,
+                                 const float* grad_memory_bias, int64_t memory_seq_len, float* grad_query, float* grad_cls, int device,
+                                 void* hip_stream) {
+    if (b < 0 || k < 0 || d <= 0 || memory_seq_len < 0) return fail(MIPS_E_INVALID, "mips_cosine_rescore_backward: bad sizes");
+    if (k > 64) return fail(MIPS_E_UNSUPPORTED, "mips_cosine_rescore_backward: k = %d > 64", k);
+    if (dtype != MIPS_DTYPE_F32 && dtype != MIPS_DTYPE_BF16) return fail(MIPS_E_INVALID, "mips_cosine_rescore_backward: dtype must be F32 or BF16");
+    if (b == 0 || k == 0) return MIPS_OK;
+    if (!query || !cls || !grad_query || !grad_cls || (!grad_scores && !grad_memory_bias))
+        return fail(MIPS_E_INVALID, "mips_cosine_rescore_backward: NULL buffer");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(MIPS_E_HIP, "hipSetDevice(%d) failed", device);
+    const float* gb = memory_seq_len > 0 ? grad_memory_bias : nullptr;
+    if (dtype == MIPS_DTYPE_F32)
+        mips::cosine_rescore_bwd_kernel<float><<<(int)b, 256, 0, (hipStream_t)hip_stream>>>((const float*)query, (const float*)cls, k, (int)d, grad_scores, gb, memory_seq_len, grad_query, grad_cls);
+    else
+        mips::cosine_rescore_bwd_kernel<uint16_t><<<(int)b, 256, 0, (hipStream_t)hip_stream>>>((const uint16_t*)query, (const uint16_t*)cls, k, (int)d, grad_scores, gb, memory_seq_len, grad_query, grad_cls);
+    HIP_TRY(hipGetLastError());
+    return MIPS_OK;
+}
+
 int mips_l2_normalize(float* x_device, int64_t n, int64_t d, int device, void* hip_stream) {
     if (n < 0 || d <= 0 || (n > 0 && !x_device)) return fail(MIPS_E_INVALID, "mips_l2_normalize: bad argument");
     if (n == 0) return MIPS_OK;
@@ -1007,7 +1032,7 @@ int mips_index_set_param(mips_index_t* ix, const char* name, int64_t value) {
     if (n == "nsplit") ix->opt_nsplit = (int)value;
     else if (n == "qgroups") ix->opt_qgroups = (int)value;
     else if (n == "variant") ix->opt_variant = (int)value;
-    else if (n == "spin_limit") ix->opt_spin_limit = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30));
+    else if (n == "spin_limit") ix->opt_spin_limit = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 30));
     else if (n == "sub") {
 #ifdef MIPS_EXPERIMENTAL
         ix->opt_sub = (int)value;

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
     const int qt = (xcd % p.qgroups) + p.qgroups * (j % p.qt_per_group);
     const int split = (xcd / p.qgroups) * p.splits_per_group + j / p.qt_per_group;
     if (qt >= p.nqt) return;
+    if (p.spin_limit < 0 && tid == 0) *p.err = 1u; // test-only: force the scan-error path (include/mips_hip.h, "spin_limit")
 
     const int b0 = split * p.tiles_per_split; // "tiles" are 32-document blocks here
     int b1 = b0 + p.tiles_per_split;

@@ -137,6 +137,10 @@ class MipsIndex:
         """Override phi (row-sharded L2 indexes: the maximum over all shards)."""
         _lib.check(self._lib.mips_index_set_phi(self._h, float(phi)), "mips_index_set_phi")
 
+    def clear_phi(self) -> None:
+        """Drop a set_phi override: phi() is this shard's own maximum again (recomputed from the stored rows)."""
+        _lib.check(self._lib.mips_index_set_phi(self._h, -1.0), "mips_index_set_phi")
+
     def rows_raw(self, row0: int = 0, n: int | None = None) -> np.ndarray:
         """Stored rows in the index dtype: np.uint16 bf16 bits, np.uint8 e4m3 codes or np.float32, [n, d]."""
         n = self.ntotal - row0 if n is None else n
@@ -257,8 +261,12 @@ class MipsIndex:
             for r0 in range(0, n, chunk_rows):
                 f.write(self.rows_raw(r0, min(chunk_rows, n - r0)).tobytes())
         meta = {"format": _FORMAT_VERSION, "d": self._d, "ntotal": n, "metric": self._metric, "dtype": self.dtype}
+        if self._metric == _lib.METRIC_L2 and n > 0:
+            # phi of the WHOLE file: a rank that loads one row range of it must not fall back to its own rows' maximum
+            # (L2 distances of different shards would not be comparable)
+            meta["phi"] = self.phi()
         if extra:
-            meta.update(extra)
+            meta.update({k: v for k, v in extra.items() if v is not None or k not in meta})
         with open(os.path.join(path, "meta.json"), "w") as f:
             json.dump(meta, f)
 
@@ -281,6 +289,8 @@ class MipsIndex:
             for r0 in range(lo, hi, chunk_rows):
                 ix.add(np.asarray(mm[r0:min(hi, r0 + chunk_rows)]))
             del mm
+        if row_range is not None and meta["metric"] == _lib.METRIC_L2 and meta.get("phi") is not None:
+            ix.set_phi(float(meta["phi"]))  # the file's phi, not this row range's
         ix.meta = meta
         return ix
 
@@ -376,34 +386,94 @@ def filter_ignore(scores, idx, ignore, k: int):
     return out_s, out_i
 
 
+def _cosine_rescore_raw(query, mips_cls, memory_seq_len: int):
+    """One launch: float32 scores [B, k] (+ memory_bias [B, k * memory_seq_len]) of CUDA query [B, d], cls [B, k, d]."""
+    import torch
+
+    lib = _lib.load()
+    b, k, d = mips_cls.shape
+    code = _lib.DTYPE_BF16 if mips_cls.dtype == torch.bfloat16 else _lib.DTYPE_F32
+    dev = query.device.index
+    out = torch.empty((b, k), dtype=torch.float32, device=query.device)
+    if memory_seq_len == 0:
+        _lib.check(lib.mips_cosine_rescore(query.data_ptr(), mips_cls.data_ptr(), code, b, k, d, out.data_ptr(), dev,
+                                           _stream_handle(dev)), "mips_cosine_rescore")
+        return out, None
+    bias = torch.empty((b, k * memory_seq_len), dtype=torch.float32, device=query.device)
+    _lib.check(lib.mips_cosine_rescore_bias(query.data_ptr(), mips_cls.data_ptr(), code, b, k, d, out.data_ptr(),
+                                            memory_seq_len, bias.data_ptr(), dev, _stream_handle(dev)),
+               "mips_cosine_rescore_bias")
+    return out, bias
+
+
+def _make_cosine_function():
+    import torch
+
+    class _CosineRescore(torch.autograd.Function):
+        """Autograd wrapper of the hook's re-score: backward = the reference's (retriever_generator.py:158-172) --
+        gradient of `query @ mips_cls.transpose(1, 2)` only, the norms are constants (they are computed under
+        torch.no_grad() there).  memory_bias is an expand of the scores, its gradient folds back over the tokens."""
+
+        @staticmethod
+        def forward(ctx, query, mips_cls, memory_seq_len):
+            ctx.save_for_backward(query, mips_cls)
+            ctx.memory_seq_len = int(memory_seq_len)
+            out, bias = _cosine_rescore_raw(query, mips_cls, ctx.memory_seq_len)
+            if bias is None:
+                return out
+            return out, bias
+
+        @staticmethod
+        def backward(ctx, g_scores, g_bias=None):
+            query, mips_cls = ctx.saved_tensors
+            lib = _lib.load()
+            b, k, d = mips_cls.shape
+            code = _lib.DTYPE_BF16 if mips_cls.dtype == torch.bfloat16 else _lib.DTYPE_F32
+            dev = query.device.index
+            gs = g_scores.float().contiguous() if g_scores is not None else None
+            gb = g_bias.float().contiguous() if (g_bias is not None and ctx.memory_seq_len > 0) else None
+            gq = torch.empty((b, d), dtype=torch.float32, device=query.device)
+            gc = torch.empty((b, k, d), dtype=torch.float32, device=query.device)
+            if gs is None and gb is None:
+                return None, None, None
+            _lib.check(lib.mips_cosine_rescore_backward(query.data_ptr(), mips_cls.data_ptr(), code, b, k, d,
+                                                        gs.data_ptr() if gs is not None else None,
+                                                        gb.data_ptr() if gb is not None else None, ctx.memory_seq_len,
+                                                        gq.data_ptr(), gc.data_ptr(), dev, _stream_handle(dev)),
+                       "mips_cosine_rescore_backward")
+            return gq.to(query.dtype), gc.to(mips_cls.dtype), None
+
+    return _CosineRescore
+
+
+_COSINE_FN = None
+
+
 def cosine_rescore(query, mips_cls, memory_seq_len: int = 0):
     """retriever_generator.py:158-172 on the device: query [B, 1, d] or [B, d], mips_cls [B, k, d]
     (CUDA float32 or bfloat16) -> float32 [B, k] = q . c / (|q| |c|).  With memory_seq_len > 0 the
     same launch also writes the hook's memory_bias (retriever_generator.py:188-192), float32
-    [B, k * memory_seq_len], and (scores, memory_bias) is returned."""
+    [B, k * memory_seq_len], and (scores, memory_bias) is returned.
+    Differentiable like the reference's expression: when an input requires grad the call goes through a
+    torch.autograd.Function whose backward (a HIP kernel as well) is the gradient of the dot product with the
+    norms held constant -- memory_bias is how the retriever's encoders are trained."""
     import torch
 
-    lib = _lib.load()
-    if query.dim() == 3:
+    global _COSINE_FN
+    squeeze_grad_shape = query.dim() == 3
+    if squeeze_grad_shape:
         query = query[:, 0, :]
     b, k, d = mips_cls.shape
     if query.shape != (b, d) or not (query.is_cuda and mips_cls.is_cuda):
         raise ValueError("cosine_rescore: expected CUDA query [B,(1,)d] and mips_cls [B,k,d]")
     if memory_seq_len < 0:
         raise ValueError("cosine_rescore: memory_seq_len must be >= 0")
-    if mips_cls.dtype == torch.bfloat16 and query.dtype == torch.bfloat16:
-        code = _lib.DTYPE_BF16
-    else:
-        query, mips_cls, code = query.float(), mips_cls.float(), _lib.DTYPE_F32
+    if not (mips_cls.dtype == torch.bfloat16 and query.dtype == torch.bfloat16):
+        query, mips_cls = query.float(), mips_cls.float()
     query, mips_cls = query.contiguous(), mips_cls.contiguous()
-    dev = query.device.index
-    out = torch.empty((b, k), dtype=torch.float32, device=query.device)
-    if memory_seq_len == 0:
-        _lib.check(lib.mips_cosine_rescore(query.data_ptr(), mips_cls.data_ptr(), code, b, k, d, out.data_ptr(), dev,
-                                           _stream_handle(dev)), "mips_cosine_rescore")
-        return out
-    bias = torch.empty((b, k * memory_seq_len), dtype=torch.float32, device=query.device)
-    _lib.check(lib.mips_cosine_rescore_bias(query.data_ptr(), mips_cls.data_ptr(), code, b, k, d, out.data_ptr(),
-                                            memory_seq_len, bias.data_ptr(), dev, _stream_handle(dev)),
-               "mips_cosine_rescore_bias")
-    return out, bias
+    if torch.is_grad_enabled() and (query.requires_grad or mips_cls.requires_grad):
+        if _COSINE_FN is None:
+            _COSINE_FN = _make_cosine_function()
+        return _COSINE_FN.apply(query, mips_cls, int(memory_seq_len))
+    out, bias = _cosine_rescore_raw(query, mips_cls, int(memory_seq_len))
+    return out if bias is None else (out, bias)

@@ -61,6 +61,8 @@ class MipsArgs:
     # backend knobs (not in the reference)
     mips_index_dtype: str = "bf16"  # "bf16" (fast path) | "fp8_e4m3" | "f32" (fp32-exact: the reference's results on fp32 data)
     mips_device: int = None
+    mips_shard: bool = False  # under an initialised torch.distributed group: row-shard the index over the ranks
+    #  instead of replicating it on every rank as lightning_model.py:180 does
 
 
 @dataclass
@@ -116,10 +118,12 @@ def retriever_metrics(pred, counts) -> dict:
     }
 
 
-def inner_product(x: np.ndarray, y: np.ndarray, k: int = 1, normalize: bool = True, device: int = None):
+def inner_product(x: np.ndarray, y: np.ndarray, k: int = 1, normalize: bool = True, device: int = None,
+                  dtype: str = "bf16"):
     """Brute-force cross-check of mips.py:552-560, run on the GPU: optional row normalisation of
     both sides, exact top-k of x @ y.T.  Scores are descending; values are the canonical scores of
-    the bf16-rounded operands."""
+    the operands as stored (dtype "bf16": rounded to bf16; "f32": the caller's fp32 values, i.e. the
+    reference's own arithmetic up to summation order)."""
     import torch
 
     assert len(x.shape) == len(y.shape) == 2
@@ -129,10 +133,48 @@ def inner_product(x: np.ndarray, y: np.ndarray, k: int = 1, normalize: bool = Tr
     if normalize:
         l2_normalize_(xd)
         l2_normalize_(yd)
-    ix = MipsIndex(y.shape[1], metric=METRIC_INNER_PRODUCT, device=device)
+    ix = MipsIndex(y.shape[1], metric=METRIC_INNER_PRODUCT, dtype=dtype, device=device)
     ix.add(yd)
     s, i = ix.search(xd, k)
     return s.cpu().numpy(), i.cpu().numpy()
+
+
+def in_batch_scores(query_cls, mips_cls, normalize: bool = False, dtype: str = "f32"):
+    """The in-batch scoring of retriever_lightning.py:304-305 (`scores = query_cls @ mips_cls.T; _, i =
+    scores.topk(1)`) and, with normalize=True, of :273-277 (`F.normalize(q) @ F.normalize(d).T`), through the
+    same search path as everything else: the B (<= 16 in the reference, at most MAX_K here) in-batch documents
+    become a B-row exact index, one search with k = B returns every score in rank order.
+    CUDA tensors [B, d] in -> (scores float32 [B, B] dense as the reference's matrix, top1 int64 [B]) on the
+    device.  dtype "f32" = fp32-exact index (the reference computes this in the model's own precision)."""
+    import torch
+
+    if not (isinstance(query_cls, torch.Tensor) and query_cls.is_cuda and isinstance(mips_cls, torch.Tensor) and mips_cls.is_cuda):
+        raise ValueError("in_batch_scores expects CUDA tensors [B, d]")
+    b, d = mips_cls.shape
+    if b > _lib.MAX_K:
+        raise NotImplementedError(f"in_batch_scores: {b} in-batch documents > MAX_K = {_lib.MAX_K}")
+    q = query_cls.detach().float().contiguous()
+    x = mips_cls.detach().float().contiguous()
+    if normalize:
+        q, x = l2_normalize_(q.clone()), l2_normalize_(x.clone())
+    ix = MipsIndex(d, metric=METRIC_INNER_PRODUCT, dtype=dtype, device=x.device.index)
+    ix.add(x)
+    s, i = ix.search(q, b)
+    dense = torch.empty_like(s).scatter_(1, i, s)
+    return dense, i[:, 0].contiguous()
+
+
+def _strip_augmentation_column(index, q: np.ndarray) -> np.ndarray:
+    """Queries prepared for the reference's L2 mode carry the zero column of augment_xq (mips.py:68-70,
+    371-372; retriever_lightning.py:313-315): [B, d + 1].  The index here stores the un-augmented d columns
+    and produces the augmented distances itself, so the column is dropped -- after checking that it IS zero
+    (anything else would change q.x' and cannot be answered from a stripped index)."""
+    if index.metric_type == METRIC_L2 and q.ndim == 2 and q.shape[1] == index.d + 1:
+        if np.any(q[:, -1] != 0):
+            raise ValueError("L2 search: the queries' last (augmentation) column is not zero; this index stores "
+                             "un-augmented rows and can only answer queries prepared by augment_xq")
+        return q[:, :-1]
+    return q
 
 
 # --------------------------------------------------------------------------- the facade
@@ -171,11 +213,54 @@ class KnowledgeBase:
     def drop_index(self, name: str):
         self._indexes.pop(name, None)
 
+    def add_faiss_index(self, column: str, index_name: str = None, device: int = None, string_factory: str = None,
+                        metric_type: int = None, custom_index=None, batch_size: int = 1000, train_size: int = None,
+                        faiss_verbose: bool = False, dtype: str = "bf16"):
+        """HF Dataset.add_faiss_index as the reference calls it (retriever_lightning.py:395-404 / pretrain.py:
+        470-479: `add_faiss_index(column="cls", index_name="mips_cls", metric_type=metric)`; mips.py:333-340 with
+        string_factory / train_size / faiss_verbose).  Builds an exact MipsIndex over `self.columns[column]`
+        ([N, d'] float32).  metric_type None = faiss.IndexFlat's default (L2), as in HF.
+          * inner product: the column is stored as it is;
+          * L2: the reference only ever indexes phi-AUGMENTED vectors here (augment_xb, retriever_lightning.py:
+            373-389): rows of constant norm sqrt(phi) whose last column is sqrt(phi - |x|^2).  The backend keeps
+            the un-augmented d = d' - 1 columns and reproduces the augmented distances |q|^2 + phi - 2 q.x, so a
+            constant-norm column is stripped of its last element; any other L2 column is refused (plain L2 on rows
+            of different norms is not this path)."""
+        if string_factory not in (None, "Flat"):
+            raise NotImplementedError(f"string_factory={string_factory!r}: only the exact 'Flat' index is implemented")
+        index_name = index_name if index_name is not None else column
+        if custom_index is not None:
+            self._indexes[index_name] = _IndexHolder(custom_index)
+            return self
+        metric = METRIC_L2 if metric_type is None else int(metric_type)
+        x = np.asarray(self.columns[column], dtype=np.float32)
+        if x.ndim != 2:
+            raise ValueError(f"add_faiss_index: column {column!r} must be a matrix [N, d], got shape {x.shape}")
+        if metric == METRIC_L2:
+            sq = np.square(x.astype(np.float64)).sum(axis=1)
+            constant_norm = x.shape[0] > 0 and x.shape[1] >= 2 and (sq.max() - sq.min()) <= 1e-4 * max(sq.max(), 1e-30)
+            if not (constant_norm and (x[:, -1] >= 0).all()):
+                raise NotImplementedError(
+                    "add_faiss_index(metric_type=L2): the rows are not phi-augmented (constant norm, last column "
+                    "sqrt(phi - |x|^2) as augment_xb produces, sotasum/mips.py:59-65); this backend's L2 is that "
+                    "MIPS->L2 reduction")
+            x = x[:, :-1]
+        elif metric != METRIC_INNER_PRODUCT:
+            raise NotImplementedError(f"metric_type={metric_type!r}: inner product (0) and L2 (1) only")
+        index = MipsIndex(x.shape[1], metric=metric, dtype=dtype, device=device)
+        index.reserve(x.shape[0])
+        for r0 in range(0, x.shape[0], max(int(batch_size), 1 << 16)):  # HF adds in batches; rows are converted on the device
+            index.add(x[r0:r0 + max(int(batch_size), 1 << 16)])
+        self._indexes[index_name] = _IndexHolder(index)
+        return self
+
     def get_nearest_examples_batch(self, index_name: str, queries, k: int = 10):
-        """HF Dataset.get_nearest_examples_batch as used at retriever_lightning.py:317-321:
-        returns (scores per query, examples per query as dict of columns); ids < 0 are dropped
-        like datasets/search.py does."""
-        s, i = self.get_index(index_name).faiss_index.search(np.ascontiguousarray(queries, dtype=np.float32), k)
+        """HF Dataset.get_nearest_examples_batch as used at retriever_lightning.py:317-321: returns (scores
+        per query, examples per query as dict of columns); ids < 0 are dropped like datasets/search.py does.
+        L2 indexes take the reference's augmented queries ([B, d + 1], zero last column) as they come."""
+        index = self.get_index(index_name).faiss_index
+        q = _strip_augmentation_column(index, np.asarray(queries, dtype=np.float32))
+        s, i = index.search(np.ascontiguousarray(q), k)
         scores, examples = [], []
         for row_s, row_i in zip(s, i):
             keep = row_i >= 0
@@ -217,7 +302,24 @@ class Mips:
         self.scale_topk = 16
 
     # ------------------------------------------------------------------ index build (mips.py:290-345)
+    def _dist(self):
+        """(rank, world, group-initialised?) of the default torch.distributed group."""
+        try:
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized():
+                return dist.get_rank(), dist.get_world_size(), True
+        except Exception:
+            pass
+        return 0, 1, False
+
+    def _sharded(self) -> bool:
+        return bool(self.args.mips_shard) and self._dist()[1] > 1
+
     def init_embeddings_folder(self) -> None:
+        """mips.py:246-249 (@rank_zero_only there)."""
+        if self._dist()[0] != 0:
+            return
         shutil.rmtree(self.embeddings_folder, ignore_errors=True)
         self.embeddings_folder.mkdir(parents=True, exist_ok=True)
 
@@ -232,18 +334,76 @@ class Mips:
         stop = min(n_rows, (rank + 1) * chunk) if rank + 1 < num_rank else n_rows
         return start, max(start, stop)
 
+    def save_embeddings_shard(self, rank: int, embeddings, columns: dict = None) -> None:
+        """What `encode_text2` leaves behind for `build_index` (mips.py:243-244: save_to_disk(embeddings_tmp/
+        <rank>)): this rank's CLS vectors [n, d] float32 (+ its slice of the text / id columns) under
+        embeddings_tmp/<rank>/.  Format: embeddings.npy + columns.json."""
+        folder = self.embeddings_tmp_folder / str(int(rank))
+        folder.mkdir(parents=True, exist_ok=True)
+        try:
+            import torch
+
+            if isinstance(embeddings, torch.Tensor):
+                embeddings = embeddings.detach().float().cpu().numpy()
+        except ImportError:
+            pass
+        np.save(folder / "embeddings.npy", np.ascontiguousarray(embeddings, dtype=np.float32))
+        with open(folder / "columns.json", "w") as f:
+            json.dump(columns if columns is not None else {}, f)
+
+    def encode_text2(self, rank: int, num_rank: int) -> None:
+        """mips.py:226-244: this rank encodes rows [rank * (N // num_rank + 1), ...) of the knowledge base and
+        saves them for `build_index`.  The encoder (SPECTER2 / Longformer, mips.py:87-151) is out of scope:
+        `self.encoder` must be a callable `list[str] -> float32 [n, d]` supplied by the caller."""
+        if self.data is None or getattr(self, "encoder", None) is None:
+            raise RuntimeError("encode_text2 needs the knowledge-base columns (data=...) and a callable self.encoder "
+                               "(texts -> [n, d] embeddings); the reference's encoders need hub weights and are not built")
+        n = len(self.data[self.text_column])
+        start, stop = self.encode_shard_bounds(n, rank, num_rank)
+        cols = {c: list(v[start:stop]) for c, v in self.data.items()}
+        bs = max(1, int(self.args.mips_batch_size))
+        parts = [np.asarray(self.encoder(cols[self.text_column][r0:r0 + bs]), dtype=np.float32)
+                 for r0 in range(0, stop - start, bs)]
+        emb = np.concatenate(parts, axis=0) if parts else np.zeros((0, 0), np.float32)
+        self.save_embeddings_shard(rank, emb, cols)
+
+    def _load_embedding_shards(self):
+        """mips.py:291-295: concatenate the per-rank shards (in rank order) -> (embeddings [N, d], columns)."""
+        folders = sorted((f for f in self.embeddings_tmp_folder.glob("*") if (f / "embeddings.npy").exists()),
+                         key=lambda f: int(f.name) if f.name.isdigit() else 1 << 30)
+        if not folders:
+            raise ValueError(f"build_index(): no embedding shards under {self.embeddings_tmp_folder} "
+                             "(encode_text2 / save_embeddings_shard write them) and no matrix was passed")
+        embs, cols = [], {}
+        for f in folders:
+            e = np.load(f / "embeddings.npy")
+            if e.size:
+                embs.append(e)
+            with open(f / "columns.json") as fh:
+                for c, v in json.load(fh).items():
+                    cols.setdefault(c, []).extend(v)
+        return embs, cols
+
     def build_index(self, embeddings=None) -> None:
         """max_norm (mips.py:298-304) -> optional document normalisation for IP (:306-314) ->
         [L2: phi, mips.py:316-324; the augmentation column is implicit in the backend] ->
-        Flat index (:333-340).  `embeddings`: float32 [N, d] NumPy array or torch tensor (the CLS
-        vectors the reference collects from per-rank shards, mips.py:292-295)."""
+        Flat index (:333-340).
+        `embeddings`: float32 [N, d] NumPy array / torch tensor, or a list of per-rank shards in rank order;
+        None = the reference's own call text (`mips.build_index()`, lightning_model.py:176): the shards that
+        encode_text2 / save_embeddings_shard left under embeddings_tmp/ are concatenated (mips.py:291-295).
+        Like the reference (@rank_zero_only, mips.py:290) only rank 0 builds when a process group is up; the
+        other ranks return at once and pick the index up in load()."""
         import torch
 
         if self.string_factory not in (None, "Flat"):
             raise NotImplementedError(
                 f"mips_string_factory={self.string_factory!r}: only the exact 'Flat' index is implemented")
+        rank, world, up = self._dist()
+        if up and rank != 0:
+            return
+        shard_cols = None
         if embeddings is None:
-            raise ValueError("build_index needs the [N, d] embedding matrix")
+            embeddings, shard_cols = self._load_embedding_shards()
         dev = f"cuda:{_lib.require_gpu(self.args.mips_device)}"
         if isinstance(embeddings, (list, tuple)):  # per-rank shards in rank order (mips.py:292-295 concatenates them)
             embeddings = torch.cat([torch.as_tensor(e).to(dev, dtype=torch.float32) for e in embeddings], dim=0)
@@ -266,8 +426,50 @@ class Mips:
             self.phi = index.phi()
         if isinstance(self.args.mips_nprobe, int):
             index.nprobe = self.args.mips_nprobe
-        cols = dict(self.data) if self.data is not None else {}
+        cols = dict(self.data) if self.data is not None else (shard_cols or {})
         self.embeddings = KnowledgeBase(cols, index, self.index_name)
+
+    def build_index_sharded(self, embeddings) -> None:
+        """Collective form of build_index for mips_shard=True: EVERY rank passes the full [N, d] matrix (array or
+        memory map) and keeps rows [r * ceil(N / G), ...) only; max_norm and phi are all-reduced (MAX) so every
+        shard normalises / measures distances like the unsharded index.  No disk round trip
+        (the reference's is mips.py:243-244 + 292-295 + 531-549)."""
+        import torch
+        import torch.distributed as dist
+
+        from .sharded import ShardedMipsIndex
+
+        if self.string_factory not in (None, "Flat"):
+            raise NotImplementedError(
+                f"mips_string_factory={self.string_factory!r}: only the exact 'Flat' index is implemented")
+        n = len(embeddings)
+        if isinstance(self.args.mips_db_max_size, int):
+            n = min(n, self.args.mips_db_max_size)
+        dev_id = _lib.require_gpu(self.args.mips_device)
+        sh = ShardedMipsIndex(int(np.shape(embeddings)[1]), metric=self.metric_type, dtype=self.args.mips_index_dtype,
+                              device=dev_id)
+        lo, hi = sh.set_global_size(n)
+        x = torch.as_tensor(np.ascontiguousarray(embeddings[lo:hi], dtype=np.float32)
+                            if not isinstance(embeddings, torch.Tensor) else embeddings[lo:hi]).to(f"cuda:{dev_id}", dtype=torch.float32).contiguous()
+        if isinstance(embeddings, torch.Tensor) and x.data_ptr() == embeddings[lo:hi].data_ptr():
+            x = x.clone()
+        local_max = rows_max_sumsq(x) if hi > lo else 0.0
+        if sh.world > 1:
+            backend = dist.get_backend()
+            t = torch.tensor([local_max], dtype=torch.float64, device=f"cuda:{dev_id}" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            local_max = float(t.item())
+        self.max_norm = float(np.sqrt(local_max))
+        if self.normalize and self.metric_type == METRIC_INNER_PRODUCT and hi > lo:
+            l2_normalize_(x)
+        if hi > lo:
+            sh.local.reserve(hi - lo)
+            sh.local.add(x)
+        sh._sync_phi()
+        if self.metric_type == METRIC_L2:
+            self.phi = sh.phi()
+        cols = dict(self.data) if self.data is not None else {}
+        self.embeddings = KnowledgeBase(cols, sh, self.index_name)
 
     # ------------------------------------------------------------------ query side
     def l2_normalization(self, x: np.ndarray) -> np.ndarray:
@@ -299,9 +501,7 @@ class Mips:
         """mips.py:382-400: k (or k+1 when filtering) nearest rows; with ignore_indexes the hit
         equal to ignore_indexes[j] is dropped per query and the rest cut to k (lists of lists)."""
         index = self._index()
-        q = np.asarray(queries)
-        if self.metric_type == METRIC_L2 and q.shape[1] == index.d + 1:
-            q = q[:, :-1]  # the augmentation column of augment_xq is identically zero
+        q = _strip_augmentation_column(index, np.asarray(queries))  # the zero column of augment_xq
         scores, indices = index.search(q, k + 1 if ignore_indexes is not None else k)
         if ignore_indexes is not None:
             out_s, out_i = [], []
@@ -330,6 +530,8 @@ class Mips:
             raise ValueError("search_device expects a CUDA tensor [B, d]")
         if prepare and self.normalize and self.metric_type == METRIC_INNER_PRODUCT:
             q = l2_normalize_(q.detach().float().contiguous().clone())
+        if q.dim() == 2 and self.metric_type == METRIC_L2 and q.shape[1] == index.d + 1:
+            q = q[:, :-1].contiguous()  # augment_xq's zero column (not checked here: that would synchronise)
         if ignore_indexes is None:
             return index.search(q, k)
         s, i = index.search(q, k + 1)
@@ -383,19 +585,39 @@ class Mips:
 
     # ------------------------------------------------------------------ persistence (mips.py:531-549)
     def save(self) -> None:
-        shutil.rmtree(self.mips_folder, ignore_errors=True)
-        self.mips_folder.mkdir(parents=True, exist_ok=True)
-        self._index().save(str(self.index_file), extra={"phi": self.phi, "normalize": bool(self.normalize)})
-        self.embeddings_folder.mkdir(parents=True, exist_ok=True)
-        with open(self.embeddings_folder / "columns.json", "w") as f:
-            json.dump(self.embeddings.columns, f)
-        with open(self.max_norm_file, "wb") as f:
-            pickle.dump(self.max_norm, f)
+        """mips.py:531-543 (@rank_zero_only there): index file + columns + max_norm.  With a row-sharded index
+        (build_index_sharded) the save is collective: every rank appends its rows to the one file set."""
+        from .sharded import ShardedMipsIndex
+
+        rank, world, up = self._dist()
+        index = self._index() if self.embeddings is not None else None
+        collective = isinstance(index, ShardedMipsIndex) and index.world > 1
+        if up and rank != 0 and not collective:
+            return
+        extra = {"phi": self.phi, "normalize": bool(self.normalize)}
+        if rank == 0:
+            shutil.rmtree(self.mips_folder, ignore_errors=True)
+            self.mips_folder.mkdir(parents=True, exist_ok=True)
+        index.save(str(self.index_file), extra=extra)
+        if rank == 0:
+            self.embeddings_folder.mkdir(parents=True, exist_ok=True)
+            with open(self.embeddings_folder / "columns.json", "w") as f:
+                json.dump(self.embeddings.columns, f)
+            with open(self.max_norm_file, "wb") as f:
+                pickle.dump(self.max_norm, f)
+            shutil.rmtree(self.embeddings_tmp_folder, ignore_errors=True)
         self.embeddings = None
-        shutil.rmtree(self.embeddings_tmp_folder, ignore_errors=True)
 
     def load(self) -> None:
-        index = MipsIndex.load(str(self.index_file), device=self.args.mips_device)
+        """mips.py:545-549: every rank loads.  The reference loads the WHOLE index on every rank
+        (lightning_model.py:180); with mips_shard=True under a process group each rank keeps only its row range
+        of the same files (ShardedMipsIndex.load) and searches go through the one all-gather + merge."""
+        if self._sharded():
+            from .sharded import ShardedMipsIndex
+
+            index = ShardedMipsIndex.load(str(self.index_file), device=self.args.mips_device)
+        else:
+            index = MipsIndex.load(str(self.index_file), device=self.args.mips_device)
         with open(self.embeddings_folder / "columns.json") as f:
             cols = json.load(f)
         self.embeddings = KnowledgeBase(cols, index, self.index_name)

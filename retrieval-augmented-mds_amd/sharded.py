@@ -70,6 +70,7 @@ class ShardedMipsIndex:
             self.local = MipsIndex(d, metric=metric, dtype=dtype, device=device)
             local_search = self.local.search
         self._fast = self.local is not None and merge is None  # both device steps are the library's own
+        self._device_merge = merge is None  # mips_merge_topk: candidates must be on the GPU whatever moved them
         if merge is None:
             from .index import merge_topk as merge
         self._local_search = local_search
@@ -104,6 +105,7 @@ class ShardedMipsIndex:
 
         if self.metric_type != _lib.METRIC_L2 or self.local is None or self.world == 1:
             return
+        self.local.clear_phi()  # a previous global value must not mask rows added since (incremental add_global)
         local = self.local.phi() if self.local.ntotal > 0 else 0.0
         backend = dist.get_backend(self.group)
         t = torch.tensor([local], dtype=torch.float64, device=f"cuda:{self.local.device}" if backend == "nccl" else "cpu")
@@ -113,6 +115,75 @@ class ShardedMipsIndex:
     @property
     def ntotal(self) -> int:
         return self.ntotal_global
+
+    @property
+    def dtype(self):
+        return self.local.dtype if self.local is not None else None
+
+    nprobe = 1  # accepted like MipsIndex.nprobe (mips.py:342-345); exact search ignores it
+
+    def phi(self) -> float:
+        """The global phi (after _sync_phi every shard holds the same override)."""
+        return self.local.phi()
+
+    # ------------------------------------------------------------------ persistence
+    def save(self, path: str, extra: dict = None) -> None:
+        """Collective: the shards are written into ONE file set in rank order (rank 0 writes meta.json), so the
+        result is the same directory MipsIndex.save produces for the unsharded index and can be loaded by any
+        number of ranks (or by a single MipsIndex.load)."""
+        import json
+        import os
+
+        import torch.distributed as dist
+
+        ext = {"bf16": "bf16", "fp8_e4m3": "e4m3", "f32": "f32"}[self.local.dtype]
+        if self.rank == 0:
+            os.makedirs(path, exist_ok=True)
+            open(os.path.join(path, "rows." + ext), "wb").close()
+        for r in range(self.world):  # append in rank order; barriers keep the order
+            if self.world > 1:
+                dist.barrier(group=self.group)
+            if r == self.rank and self.local.ntotal > 0:
+                with open(os.path.join(path, "rows." + ext), "ab") as f:
+                    n = self.local.ntotal
+                    for r0 in range(0, n, 1 << 16):
+                        f.write(self.local.rows_raw(r0, min(1 << 16, n - r0)).tobytes())
+        if self.world > 1:
+            dist.barrier(group=self.group)
+        if self.rank == 0:
+            meta = {"format": 1, "d": self.d, "ntotal": self.ntotal_global, "metric": self.metric_type,
+                    "dtype": self.local.dtype}
+            if self.metric_type == _lib.METRIC_L2 and self.ntotal_global > 0:
+                meta["phi"] = self.phi()
+            if extra:
+                meta.update({k: v for k, v in extra.items() if v is not None or k not in meta})
+            with open(os.path.join(path, "meta.json"), "w") as f:
+                json.dump(meta, f)
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
+    @classmethod
+    def load(cls, path: str, group=None, device=None) -> "ShardedMipsIndex":
+        """Every rank maps the same file set and keeps its own row range (MipsIndex.load(row_range)); an L2
+        index takes the file's global phi.  Replaces `load()` on every rank of lightning_model.py:180."""
+        import json
+        import os
+
+        from .index import MipsIndex
+
+        with open(os.path.join(path, "meta.json")) as f:
+            meta = json.load(f)
+        self = cls.__new__(cls)
+        ShardedMipsIndex.__init__(self, meta["d"], metric=meta["metric"], dtype=meta["dtype"], group=group, device=device,
+                                  local_search=lambda *a, **k: None)  # placeholder: the local index comes from the file
+        lo, hi = self.set_global_size(meta["ntotal"])
+        self.local = MipsIndex.load(path, device=device, row_range=(lo, hi))
+        self._local_search = self.local.search
+        self._fast = True
+        self.meta = meta
+        if self.metric_type == _lib.METRIC_L2 and meta.get("phi") is None:
+            self._sync_phi()  # files written before phi was persisted
+        return self
 
     def check(self, synchronize: bool = True) -> None:
         """MipsIndex.check for this rank's shard.  A shard whose scan timed out hands poisoned rows (idx -2, NaN)
@@ -177,11 +248,17 @@ class ShardedMipsIndex:
         return ShardedMipsIndex._Pending(out, done, (packed, gathered), self.local)
 
     # ------------------------------------------------------------------ search
-    def search(self, q, k: int):
-        """Replicated queries in, global top-k out (same on every rank)."""
+    def search(self, q, k: int, idx_offset: int = 0, force_ip: bool = False):
+        """Replicated queries in, global top-k out (same on every rank).  force_ip: rank by inner product on an
+        L2 index (Mips.np_search); idx_offset exists for signature compatibility with MipsIndex.search and must
+        be 0 (global row numbers are the shard offsets' business)."""
         import torch
         import torch.distributed as dist
 
+        if idx_offset:
+            raise ValueError("ShardedMipsIndex.search returns global row numbers; idx_offset must be 0")
+        if force_ip:
+            return self._search_force_ip(q, k)
         backend = dist.get_backend(self.group) if self.world > 1 else None
         if (self.world > 1 and self.local is not None and self._fast and isinstance(q, torch.Tensor) and q.is_cuda):
             # device fast path: the re-score kernel writes the all-gather payload, the merge kernel reads
@@ -198,13 +275,25 @@ class ShardedMipsIndex:
                 gathered = gathered.to(q.device)
             return merge_topk_packed(gathered, nq, self.world, k, self.metric_type)
         s, i = self._local_search(q, k, self.lo)
+        return self._exchange(s, i, k, self.metric_type)
+
+    def _search_force_ip(self, q, k: int):
+        s, i = self.local.search(q, k, self.lo, force_ip=True)
+        return self._exchange(s, i, k, _lib.METRIC_IP)
+
+    def _exchange(self, s, i, k: int, metric: int):
+        """Generic form of the exchange step: pack the local top-k, ONE all-gather, unpack, merge."""
+        import torch
+        import torch.distributed as dist
+
         if self.world == 1:
             return s, i
+        backend = dist.get_backend(self.group)
         as_numpy = not isinstance(s, torch.Tensor)
         if as_numpy:
             s, i = torch.from_numpy(np.ascontiguousarray(s)), torch.from_numpy(np.ascontiguousarray(i))
         home = s.device
-        if backend == "nccl" and not s.is_cuda:
+        if (backend == "nccl" or self._device_merge) and not s.is_cuda:
             home = torch.device(f"cuda:{self.local.device}" if self.local is not None else "cuda")
             s, i = s.to(home), i.to(home)
         packed = pack_topk(s, i)
@@ -217,7 +306,7 @@ class ShardedMipsIndex:
         if gathered.device != home:
             gathered = gathered.to(home)
         cs, ci = unpack_gathered(gathered.view((self.world, nq) + tuple(packed.shape[1:])), self.world)
-        out_s, out_i = self._merge(cs, ci, self.world, k, self.metric_type)
+        out_s, out_i = self._merge(cs, ci, self.world, k, metric)
         if as_numpy:
             return out_s.cpu().numpy(), out_i.cpu().numpy()
         return out_s, out_i

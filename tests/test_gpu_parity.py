@@ -917,10 +917,353 @@ def test_experimental_scan_variants_are_bit_identical():
     x = synth.generate(171, 0, n, d, synth.KIND_GAUSS)
     es, ei = orc.search_exact(q.float().cpu().numpy()[:64], x, k)
     assert np.array_equal(ref_i[:64].cpu().numpy(), ei) and np.array_equal(ref_s[:64].cpu().numpy(), es)
-    for params in ({"variant": 4}, {"variant": 3}, {"variant": 3, "sub": 10}, {"variant": 3, "sub": 11}, {"variant": 3, "sub": 3},
-                   {"variant": 3, "sub": 4}, {"variant": 3, "sub": 6}, {"variant": 3, "sub": 15}, {"variant": 3, "sub": 7},
-                   {"variant": 1}, {"variant": 3, "nsplit": 40}, {"variant": 3, "qgroups": 2}, {"variant": 4, "nsplit": 8}):
-        for name in ("variant", "sub", "nsplit", "qgroups"):
+    for params in ({"variant": 4}, {"variant": 3}, {"variant": 1}, {"variant": 3, "nsplit": 40}, {"variant": 3, "qgroups": 2},
+                   {"variant": 4, "nsplit": 8}, {"variant": 4, "qgroups": 4}):
+        for name in ("variant", "nsplit", "qgroups"):
             ix.set_param(name, params.get(name, 0))
         s, i = ix.search(q, k)
         assert torch.equal(i, ref_i) and torch.equal(s, ref_s), params
+    # the experimental `sub` instances (two of them wrong by design) are not in the shipped library
+    with pytest.raises(RuntimeError, match="experimental"):
+        ix.set_param("sub", 8)
+    ix.set_param("sub", 0)
+
+
+# ------------------------------------------------------------------ scan-error word on every path
+def test_scan_timeout_poisons_and_raises_on_every_path():
+    """A scan kernel whose block barrier gives up must never return plausible garbage.  "spin_limit" = -1 makes
+    every launch raise its error word (test-only knob): the exact re-score then writes idx = IDX_POISON / NaN
+    into every slot, raises the sticky host flag, and the failure surfaces as RuntimeError -- on the host path at
+    once, on the device-output / packed / sharded paths through check() or the next call; the cross-shard merge
+    propagates poison so a timed-out shard cannot drop out of a global top-k silently."""
+    n, d, nq, k = 60000, 768, 700, 5
+    for dtype in ("bf16", "fp8_e4m3"):
+        ix = ram.MipsIndex(d, dtype=dtype)
+        ix.add_synthetic(n, 0, synth.SEED_DOCS, synth.KIND_GAUSS)
+        q = ram.synth_fill(nq, d, 0, synth.SEED_QUERIES, synth.KIND_GAUSS)
+        ref_s, ref_i = ix.search(q, k)
+        ix.check()                                                    # healthy index: nothing raised
+        for variant, nqq in ((0, nq), (3, nq), (0, 100)):             # v4 / f8x, v3 / f8, single-tile nt kernel
+            ix.set_param("variant", variant)
+            ix.set_param("spin_limit", -1)
+            s, i = ix.search(q[:nqq], k)                              # device output: no exception here
+            torch.cuda.synchronize()
+            assert (i == ram.IDX_POISON).all() and torch.isnan(s).all(), (dtype, variant)
+            with pytest.raises(RuntimeError, match="gave up"):
+                ix.check()
+            ix.check()                                                # reported once, then cleared
+            p = ix.search_packed(q[:nqq], k, 1000)                    # the all-gather payload is poisoned as well
+            torch.cuda.synchronize()
+            assert (p[..., 1] == ram.IDX_POISON).all()
+            with pytest.raises(RuntimeError, match="gave up"):        # ... and the NEXT call on the index reports it
+                ix.search(q[:nqq], k)
+            with pytest.raises(RuntimeError, match="gave up"):        # host buffers: raised by the call itself
+                ix.search(q[:nqq].float().cpu().numpy(), k)
+            ix.set_param("spin_limit", 0)
+            s, i = ix.search(q[:nqq], k)
+            ix.check()
+            assert torch.equal(i, ref_i[:nqq]) and torch.equal(s, ref_s[:nqq]), (dtype, variant)
+        ix.set_param("variant", 0)
+    # a tiny REAL spin bound: either nothing timed out (results exact) or the call is poisoned and reported
+    ix = ram.MipsIndex(d)
+    ix.add_synthetic(n, 0, synth.SEED_DOCS, synth.KIND_GAUSS)
+    ref_s, ref_i = ix.search(q, k)
+    ix.set_param("spin_limit", 1)
+    s, i = ix.search(q, k)
+    torch.cuda.synchronize()
+    if (i == ram.IDX_POISON).any():
+        assert (i == ram.IDX_POISON).all() and torch.isnan(s).all()
+        with pytest.raises(RuntimeError, match="gave up"):
+            ix.check()
+    else:
+        ix.check()
+        assert torch.equal(i, ref_i) and torch.equal(s, ref_s)
+    ix.set_param("spin_limit", 0)
+    # merge kernels: one poisoned shard poisons the merged rows
+    good = ix.search_packed(q, k, 0)
+    bad = good.clone()
+    bad[5] = torch.tensor([0x7fc00000, ram.IDX_POISON], device="cuda")
+    ms, mi = ram.merge_topk_packed(torch.cat([good, bad], 0), nq, 2, k)
+    assert (mi[5] == ram.IDX_POISON).all() and torch.isnan(ms[5]).all() and (mi[:5] >= 0).all() and (mi[6:] >= 0).all()
+    cs = torch.cat([ref_s, ref_s], 1)
+    ci = torch.cat([ref_i, ref_i + n], 1)
+    ci[7, 3] = ram.IDX_POISON
+    ms, mi = ram.merge_topk(cs, ci, 2, k)
+    assert (mi[7] == ram.IDX_POISON).all() and torch.isnan(ms[7]).all() and (mi[8] >= 0).all()
+
+
+def _timeout_worker(rank, world, port, ret):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        sh = ram.ShardedMipsIndex(768, device=0)
+        sh.add_synthetic_global(40000, synth.SEED_DOCS, synth.KIND_GAUSS)
+        q = ram.synth_fill(300, 768, 0, synth.SEED_QUERIES, synth.KIND_GAUSS)
+        ref = sh.search(q, 5)
+        if rank == 1:
+            sh.local.set_param("spin_limit", -1)                      # only rank 1's shard times out
+        s, i = sh.search(q, 5)
+        torch.cuda.synchronize()
+        poisoned = bool((i == ram.IDX_POISON).all() and torch.isnan(s).all())   # EVERY rank sees it in the results
+        raised = False
+        try:
+            sh.check()
+        except RuntimeError:
+            raised = True
+        sh.local.set_param("spin_limit", 0)
+        s2, i2 = sh.search(q, 5)
+        ret[rank] = (poisoned, raised, bool(torch.equal(i2, ref[1]) and torch.equal(s2, ref[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_scan_timeout_on_one_shard_reaches_every_rank():
+    import torch.multiprocessing as mp
+
+    ret = mp.Manager().dict()
+    mp.spawn(_timeout_worker, args=(2, 29900 + (os.getpid() % 1500), ret), nprocs=2, join=True)
+    assert dict(ret) == {0: (True, False, True), 1: (True, True, True)}
+
+
+# ------------------------------------------------------------------ a9 / f4: the full-KB eval consumer, a10: in-batch scoring
+@pytest.mark.parametrize("d", [768, 1024])
+@pytest.mark.parametrize("inner_product", [False, True])
+def test_full_kb_eval_call_text(d, inner_product):
+    """retriever_lightning.py:372-404 + 313-321 replayed against KnowledgeBase: phi-augment the `cls` column
+    (default, L2) or keep it (inner_product=True), `add_faiss_index(column="cls", index_name="mips_cls",
+    metric_type=metric)`, then `get_nearest_examples_batch("mips_cls", queries=augment_xq(q) | q, k=top_k)`."""
+    n, nq, top_k = 6000, 16, 5
+    rng = np.random.default_rng(d)
+    cls = (synth.generate(201, 0, n, d, synth.KIND_GAUSS) * rng.uniform(0.4, 1.6, (n, 1))).astype(np.float32)
+    query_cls = synth.generate(202, 0, nq, d, synth.KIND_GAUSS)
+    kb_cols = {"mips_column": [f"abstract {t}" for t in range(n)], "aid": [[f"a{t}", f"b{t % 7}"] for t in range(n)]}
+    column, metric = orc.full_kb_eval_index(cls, inner_product)                 # what the reference puts into "cls"
+    kb = ram.KnowledgeBase(dict(kb_cols, cls=column))
+    kb.add_faiss_index(column="cls", index_name="mips_cls", metric_type=metric)
+    q = query_cls if inner_product else ram.augment_xq(query_cls)               # :313-315
+    scores, examples = kb.get_nearest_examples_batch("mips_cls", queries=q, k=top_k)
+    index = kb.get_index("mips_cls").faiss_index
+    assert index.d == d and index.metric_type == metric and index.ntotal == n
+    stored = synth.bf16_bits_to_f32(index.rows_bf16())
+    np.testing.assert_array_equal(stored, synth.round_to_bf16(cls))             # the augmentation column is not stored
+    es, ex = orc.nearest_examples_batch(lambda qq, kk: orc.search_exact(synth.round_to_bf16(qq[:, :d]), stored, kk, metric=metric),
+                                        kb_cols, q, top_k)
+    assert len(scores) == nq and all(np.array_equal(a, b) for a, b in zip(scores, es))
+    assert [e["aid"] for e in examples] == [e["aid"] for e in ex]
+    assert [e["mips_column"] for e in examples] == [e["mips_column"] for e in ex]
+    if not inner_product:
+        # the distances are those of brute force on the reference's augmented fp32 vectors (1e-3: bf16 storage)
+        d2 = ((orc.augment_xq(query_cls).astype(np.float64)[:, None, :] - column.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+        np.testing.assert_allclose(np.stack(scores), np.sort(d2, axis=1)[:, :top_k], rtol=2e-2)
+        with pytest.raises(ValueError, match="not zero"):
+            bad = q.copy()
+            bad[0, -1] = 1.0
+            kb.get_nearest_examples_batch("mips_cls", queries=bad, k=top_k)
+        with pytest.raises(NotImplementedError, match="phi-augmented"):
+            ram.KnowledgeBase(dict(cls=cls)).add_faiss_index(column="cls", metric_type=ram.METRIC_L2)   # not augmented
+    # metrics of :327-335 on CUDA tensors == the oracle's (golden G4 pins the oracle)
+    pred = torch.tensor([[f"a{int(ex[j]['aid'][0][0][1:])}" in a for a in e["aid"]] for j, e in enumerate(examples)]).float()
+    counts = torch.ones(nq)
+    assert ram.retriever_metrics(pred.cuda(), counts.cuda()) == pytest.approx(orc.retriever_metrics(pred, counts))
+
+
+def test_fp32_exact_eval_index_returns_the_reference_neighbours():
+    """The same call text on plain fp32 embeddings with dtype="f32": the neighbours of an fp64 brute force on the
+    reference's augmented vectors, distances to fp32 rounding."""
+    n, d, nq, top_k = 5000, 768, 16, 5
+    rng = np.random.default_rng(5)
+    cls = (rng.standard_normal((n, d)) * rng.uniform(0.4, 1.6, (n, 1))).astype(np.float32)
+    query_cls = rng.standard_normal((nq, d)).astype(np.float32)
+    column, metric = orc.full_kb_eval_index(cls, False)
+    kb = ram.KnowledgeBase(dict(cls=column, mips_column=list(range(n))))
+    kb.add_faiss_index(column="cls", index_name="mips_cls", metric_type=metric, dtype="f32")
+    scores, examples = kb.get_nearest_examples_batch("mips_cls", queries=ram.augment_xq(query_cls), k=top_k)
+    d2 = ((orc.augment_xq(query_cls).astype(np.float64)[:, None, :] - column.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+    assert [e["mips_column"] for e in examples] == np.argsort(d2, axis=1)[:, :top_k].tolist()
+    np.testing.assert_allclose(np.stack(scores), np.sort(d2, axis=1)[:, :top_k], rtol=1e-4)
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+def test_in_batch_scoring(normalize):
+    """a10 -- retriever_lightning.py:304-305 (and the normalised form of :273-277), B = 16, topk(1)."""
+    torch.manual_seed(3)
+    b, d = 16, 768
+    query_cls = torch.randn(b, d)
+    mips_cls = query_cls[torch.randperm(b)] * 0.8 + 0.6 * torch.randn(b, d)      # a noisy permutation: top-1 is non-trivial
+    es, ei = orc.in_batch_scores(query_cls, mips_cls, normalize)
+    s, i = ram.in_batch_scores(query_cls.cuda(), mips_cls.cuda(), normalize=normalize)
+    assert s.shape == (b, b) and torch.equal(i.cpu(), ei)
+    torch.testing.assert_close(s.cpu(), es, rtol=1e-3, atol=1e-5)                # north-star tolerance on scores
+    acc = (i.cpu() == torch.arange(b)).float().mean()                             # :306-308 consume it like this
+    assert acc == (ei == torch.arange(b)).float().mean()
+    s16, i16 = ram.in_batch_scores(query_cls.cuda().bfloat16(), mips_cls.cuda().bfloat16(), normalize=normalize)
+    assert i16.shape == (b,)
+
+
+def test_inner_product_normalized_matches_reference_golden(golden_dir):
+    """Golden G2: the REAL reference inner_product(..., normalize=True) on the config-1 shape."""
+    g = np.load(os.path.join(golden_dir, "g1_g2_inner_product.npz"))
+    x = synth.generate(int(g["seed_docs"]), 0, int(g["n"]), int(g["d"]), int(g["kind"]))
+    s, i = ram.inner_product(g["queries"], x, k=int(g["k"]), normalize=True)
+    assert np.array_equal(i, g["indices_norm"])
+    np.testing.assert_allclose(s, g["scores_norm"], rtol=1e-3)
+    s32, i32 = ram.inner_product(g["queries"], x, k=int(g["k"]), normalize=True, dtype="f32")
+    assert np.array_equal(i32, g["indices_norm"])
+    np.testing.assert_allclose(s32, g["scores_norm"], rtol=2e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------ the hook's re-score is differentiable like the reference's
+def test_cosine_rescore_gradients_match_the_reference_expression():
+    """retriever_generator.py:158-172: only the norms are under no_grad; memory_bias carries the retrieval
+    gradient to the query / memory encoders.  Gradient parity with the torch expression, fp32 and bf16."""
+    torch.manual_seed(1)
+    b, k, d, mem_len = 6, 5, 768, 37
+    for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+        q0 = torch.randn(b, 1, d, device="cuda").to(dt)
+        c0 = torch.randn(b, k, d, device="cuda").to(dt)
+        w_s = torch.randn(b, k, device="cuda")
+        w_b = torch.randn(b, k * mem_len, device="cuda")
+        # reference expression (oracle restatement with the norms under no_grad, as in the reference)
+        q, c = q0.clone().float().requires_grad_(True), c0.clone().float().requires_grad_(True)
+        sc = (q @ c.transpose(1, 2)).squeeze(1)
+        with torch.no_grad():
+            nrm = (torch.norm(q, dim=2, keepdim=True) * torch.norm(c, dim=2, keepdim=True)).squeeze(2)
+        sc = sc / nrm
+        bias = orc.memory_bias(sc, mem_len)
+        ((sc * w_s).sum() + (bias * w_b).sum()).backward()
+        # product
+        q2, c2 = q0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+        sc2, bias2 = ram.cosine_rescore(q2, c2, memory_seq_len=mem_len)
+        assert sc2.requires_grad and bias2.requires_grad
+        ((sc2 * w_s).sum() + (bias2 * w_b).sum()).backward()
+        assert q2.grad.shape == q0.shape and c2.grad.shape == c0.shape and q2.grad.dtype == dt
+        torch.testing.assert_close(sc2, sc.detach(), rtol=1e-5, atol=2e-6)
+        torch.testing.assert_close(q2.grad.float(), q.grad, rtol=tol, atol=tol * q.grad.abs().max().item())
+        torch.testing.assert_close(c2.grad.float(), c.grad, rtol=tol, atol=tol * c.grad.abs().max().item())
+        # scores only (no bias), and no graph when nothing requires grad
+        q3 = q0.clone().requires_grad_(True)
+        sc3 = ram.cosine_rescore(q3, c0)
+        sc3.sum().backward()
+        assert q3.grad is not None and not ram.cosine_rescore(q0, c0).requires_grad
+
+
+# ------------------------------------------------------------------ the facade row-shards under a process group
+def _facade_shard_worker(rank, world, port, tmp, ret):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        n, d, k = 9001, 768, 5
+        rng = np.random.default_rng(17)
+        emb = (synth.generate(211, 0, n, d, synth.KIND_GAUSS) * rng.uniform(0.3, 2.2, (n, 1))).astype(np.float32)
+        qs = synth.generate(212, 0, 8, d, synth.KIND_GAUSS)
+        data = {"mips_column": [f"text {t}" for t in range(n)], "aid": [f"a{t}" for t in range(n)]}
+        ok = True
+        for metric, normalize in ((0, True), (1, True)):
+            folder = os.path.join(tmp, f"m{metric}")
+            args = ram.MipsArgs(mips_metric_type=metric, mips_normalize=normalize, mips_tmp_folder=folder, mips_shard=True,
+                                mips_device=0, mips_batch_size=1000)
+            m = ram.Mips(args, data=data)
+            m.encoder = lambda texts: emb[[int(t.split()[1]) for t in texts]]   # stands in for the SPECTER2 encoder
+            # ---- the call text of lightning_model.py:168-180, unchanged
+            m.init_embeddings_folder()
+            dist.barrier()
+            m.encode_text2(rank=rank, num_rank=world)
+            dist.barrier()
+            m.build_index()
+            m.save()
+            dist.barrier()
+            m.rebuilt_steps.append(1)
+            m.load()
+            # ----
+            index = m.embeddings.get_index(m.index_name).faiss_index
+            lo, hi = ram.shard_bounds(n, world, rank)
+            ok &= isinstance(index, ram.ShardedMipsIndex) and index.local.ntotal == hi - lo and index.ntotal == n
+            whole = ram.Mips(ram.MipsArgs(mips_metric_type=metric, mips_normalize=normalize, mips_tmp_folder=folder, mips_device=0))
+            whole.load()                                                         # the reference's replicated form
+            ok &= isinstance(whole.embeddings.get_index(m.index_name).faiss_index, ram.MipsIndex)
+            pq = m._prepare_query(qs.copy())
+            s1, i1 = whole.search(pq, k=k)
+            s2, i2 = m.search(pq, k=k)
+            ok &= np.array_equal(i1, i2) and np.array_equal(s1, s2)
+            ignore = [int(i1[j][j % k]) for j in range(8)]
+            a, b = whole.search(pq, ignore_indexes=ignore, k=k), m.search(pq, ignore_indexes=ignore, k=k)
+            ok &= [list(map(int, r)) for r in a[1]] == [list(map(int, r)) for r in b[1]] and \
+                [list(map(float, r)) for r in a[0]] == [list(map(float, r)) for r in b[0]]
+            qd = torch.from_numpy(qs).cuda()
+            ds1, di1 = whole.search_device(qd, ignore_indexes=torch.tensor(ignore).cuda(), k=k)
+            ds2, di2 = m.search_device(qd, ignore_indexes=torch.tensor(ignore).cuda(), k=k)
+            ok &= torch.equal(di1, di2) and torch.equal(ds1, ds2)
+            n1, n2 = whole.np_search(qs, k), m.np_search(qs, k)
+            ok &= np.array_equal(n1[1], n2[1]) and np.array_equal(n1[0], n2[0])
+            out1, out2 = whole.forward(qs.copy(), k=k), m.forward(qs.copy(), k=k)
+            ok &= out1.examples == out2.examples and m.max_norm == whole.max_norm and m.phi == whole.phi
+            # vs the oracle on the stored rows
+            stored = synth.bf16_bits_to_f32(whole.embeddings.get_index(m.index_name).faiss_index.rows_bf16())
+            es, ei = orc.search_exact(synth.round_to_bf16(pq[:, :d]), stored, k, metric=metric)
+            ok &= np.array_equal(i2, ei) and np.array_equal(s2, es)
+            # ---- collective build without the disk round trip, then a collective save read back by one process
+            c = ram.Mips(ram.MipsArgs(mips_metric_type=metric, mips_normalize=normalize, mips_tmp_folder=folder + "c",
+                                      mips_shard=True, mips_device=0), data=data)
+            c.build_index_sharded(emb)
+            s3, i3 = c.search(pq, k=k)
+            ok &= np.array_equal(i3, i1) and np.array_equal(s3, s1) and c.max_norm == pytest.approx(whole.max_norm, rel=1e-12)
+            ok &= (c.phi == whole.phi)
+            c.save()
+            dist.barrier()
+            back = ram.Mips(ram.MipsArgs(mips_metric_type=metric, mips_normalize=normalize, mips_tmp_folder=folder + "c", mips_device=0))
+            back.load()
+            s4, i4 = back.search(pq, k=k)
+            ok &= np.array_equal(i4, i1) and np.array_equal(s4, s1)
+            dist.barrier()
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_facade_row_shards_under_a_process_group(tmp_path):
+    """MipsArgs.mips_shard: the reference's own rebuild call text (lightning_model.py:168-180) leaves every rank
+    with ITS row range of the index; Mips.search / search_device / np_search / forward return what the replicated
+    index returns, bit for bit, inner product and L2 (2 gloo ranks sharing cuda:0)."""
+    import torch.multiprocessing as mp
+
+    ret = mp.Manager().dict()
+    mp.spawn(_facade_shard_worker, args=(2, 29300 + (os.getpid() % 1500), str(tmp_path), ret), nprocs=2, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_sharded_l2_save_load_and_incremental_add(tmp_path):
+    """(1) MipsIndex.save persists phi and load(row_range) restores the FILE's phi, so a shard loaded
+    alone measures the same distances as the whole index; (2) after set_phi an incremental add followed by
+    _sync_phi sees the new, larger norms."""
+    n, d, k = 8000, 256, 4
+    rng = np.random.default_rng(9)
+    x = synth.round_to_bf16((synth.generate(221, 0, n, d, synth.KIND_GAUSS) * rng.uniform(0.3, 2.5, (n, 1))).astype(np.float32))
+    x[n - 1] *= 4.0                                                   # the global maximum norm sits in the LAST shard
+    x = synth.round_to_bf16(x)
+    q = synth.generate(222, 0, 12, d, synth.KIND_GAUSS)
+    full = _index(x, metric=ram.METRIC_L2)
+    fs, fi = full.search(q, k)
+    full.save(str(tmp_path / "l2"))
+    parts = [ram.MipsIndex.load(str(tmp_path / "l2"), row_range=ram.shard_bounds(n, 2, r)) for r in range(2)]
+    assert parts[0].phi() == parts[1].phi() == full.phi()
+    out = [p.search(torch.from_numpy(q).cuda(), k, ram.shard_bounds(n, 2, r)[0]) for r, p in enumerate(parts)]
+    ms, mi = ram.merge_topk(torch.cat([o[0] for o in out], 1), torch.cat([o[1] for o in out], 1), 2, k, metric=ram.METRIC_L2)
+    assert np.array_equal(mi.cpu().numpy(), fi) and np.array_equal(ms.cpu().numpy(), fs)
+    es, ei = orc.search_exact(q, x, k, metric=orc.METRIC_L2)
+    assert np.array_equal(fi, ei) and np.array_equal(fs, es)
+    # (2) override, add bigger rows, drop the override: phi follows
+    p0 = parts[0]
+    old = p0.phi()
+    big = synth.round_to_bf16(x[:3] * 50.0)
+    p0.add(big)
+    assert p0.phi() == old                                            # still the override
+    p0.clear_phi()
+    assert p0.phi() > old and p0.phi() == pytest.approx(float((big.astype(np.float64) ** 2).sum(1).max()), rel=1e-12)

@@ -58,7 +58,7 @@ class OracleIndex:
     def __init__(self, x, metric=0):
         self.x = synth.round_to_bf16(np.asarray(x, dtype=np.float32))
         self.d = self.x.shape[1]
-        self.metric = metric
+        self.metric = self.metric_type = metric  # faiss.Index.metric_type
         self.calls = []
 
     @property
