@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks ITSELF (a child
+`python -m torch.distributed.run ...` of this same file, spawned before this process touches the GPU), relays
+the child's output and exits with its code -- so the same verb produces a 1-GPU and an N-GPU line.
+
 A step = one pass of the hot path over one batch: Q = 4096 synthetic bf16 queries (already resident
 in HBM) against the HBM-resident 2^20 x 768 bf16 index (BASELINE config 2), top-k = 5, through
 MipsIndex.search -> mips_search (query staging into the padded tile buffer, fused MFMA score +
@@ -12,15 +16,20 @@ top-K scan, split merge + exact re-score).  With N > 1 the SAME index is row-sha
 (rank r keeps rows [r*ceil(n/N), ...)), every rank scores all queries against its shard and one
 RCCL all-gather + merge produces the replicated global top-k: total work is fixed => "strong".
 
-One JSON line on rank 0.  `roofline` describes the dominant kernel (scan_kernel): this workload
-has Q = 4096 flop per index byte, far above the ~310 flop/B ridge, so the binding roof is MFMA;
-the HBM-read fraction the north star asks for is reported next to it (hbm_* keys).
-`cpu_baseline` times the oracle's literal restatement of the reference's brute force
-(sotasum/mips.py:552-560: fp32 matmul + full argsort) on the host cores, rank 0, N = 1 only.
+One JSON line on rank 0.  `roofline` describes the dominant kernel (the fused scan; its name comes from the
+library: mips_index_last_kernel): this workload has Q = 4096 flop per index byte, far above the ~310 flop/B
+ridge, so the binding roof is MFMA; the HBM-read fraction the north star asks for is reported next to it
+(hbm_* keys) and measured where it is meaningful in `regimes` (2^24 x 768 index at Q = 8: HBM-bound).
+`cpu_baseline` times the oracle's literal restatement of the reference's brute force (sotasum/mips.py:552-560:
+fp32 matmul + full argsort), `cpu_baseline_torch` the reference's CPU torch idiom (retriever_lightning.py:304-305,
+`topk(q @ d.T)`) on all host cores; rank 0, N = 1 only, bounded samples, >= 3 repeats, median.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -42,20 +51,45 @@ def parse():
     ap.add_argument("--queries", type=int, default=4096)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=5)
-    ap.add_argument("--cpu-queries", type=int, default=768, help="queries in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-queries", type=int, default=256, help="queries per repeat of the NumPy-port CPU baseline")
+    ap.add_argument("--cpu-torch-queries", type=int, default=1024, help="queries per repeat of the torch CPU baseline")
+    ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-regimes", action="store_true", help="skip the 2^24-row regime measurements (N = 1 only)")
     ap.add_argument("--index-dtype", default="bf16", choices=["bf16", "fp8_e4m3"],
                     help="fp8_e4m3 = BASELINE config 5 (index and queries quantised to OCP e4m3, fp8 MFMA)")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: run every step's all-gather + merge before the next scan")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N > 1 path on ONE GPU (all ranks on cuda:0, host-staged collective)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="form the N-rank process group, exchange one tensor, print what was formed and exit (no search, no GPU)")
     return ap.parse_args()
 
 
-def cpu_baseline(index, q_dev, args):
-    """Reference-faithful CPU path (oracle port of mips.py:552-560) on a bounded sample: the first
-    `cpu_queries` queries against the full index (values read back from HBM, up-cast to fp32)."""
+def self_launch(args) -> int:
+    """--gpus N > 1 without WORLD_SIZE: start N ranks as a child torch.distributed.run of this file.  Nothing in
+    this process has touched the GPU yet (only argparse ran), and nothing is exec'ed: the child is a subprocess and
+    this process exits with its code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MIPS_BENCH_SELF_LAUNCHED"] = "1"
+    print(f"[bench] --gpus {args.gpus}: launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def cpu_baselines(index, q_dev, args):
+    """Both CPU baselines on bounded samples of the SAME workload (values read back from HBM, up-cast to fp32),
+    >= 3 repeats each, median reported:
+      port   oracle.inner_product = the literal NumPy restatement of mips.py:552-560 (matmul + full argsort)
+      torch  oracle.torch_topk    = torch.topk(q @ d.T, k) on all host cores, 256-query chunks over <= 2^20-row
+                                    document blocks with a running top-k merge"""
     import numpy as np
+    import torch
 
     from oracle import mips_oracle as orc
     from oracle import synth
@@ -66,46 +100,148 @@ def cpu_baseline(index, q_dev, args):
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         threads = os.cpu_count() or 1
-    nq = min(args.cpu_queries, args.queries)
     x = synth.bf16_bits_to_f32(index.rows_raw()) if index.dtype == "bf16" else synth.e4m3_bits_to_f32(index.rows_raw())
-    q = q_dev[:nq].float().cpu().numpy()
+    qa = q_dev.float().cpu().numpy()
     if index.dtype != "bf16":
-        q = synth.round_to_e4m3(q)  # the device quantises the queries the same way
-    orc.inner_product(q[:2], x[:4096], k=args.k, normalize=False)  # warm-up
-    t0 = time.perf_counter()
-    s, i = orc.inner_product(q, x, k=args.k, normalize=False)
-    dt = time.perf_counter() - t0
-    return {
-        "value": nq / dt, "unit": "queries/s", "cores": int(threads), "kind": "port",
-        "sample": f"{nq} of {args.queries} queries x full {x.shape[0]}x{x.shape[1]} index (fp32 up-cast of the "
-                  f"bf16 values), NumPy matmul + full argsort = oracle.inner_product (mips.py:552-560), "
-                  f"{dt:.2f} s; argsort is single-threaded, matmul uses {threads} BLAS threads; "
-                  f"host has {os.cpu_count()} logical cores",
-    }, (s, i)
+        qa = synth.round_to_e4m3(qa)  # the device quantises the queries the same way
+    reps = max(1, args.cpu_repeats)
+
+    nq = min(args.cpu_queries, args.queries)
+    orc.inner_product(qa[:2], x[:4096], k=args.k, normalize=False)  # warm-up
+    times, res = [], None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        res = orc.inner_product(qa[:nq], x, k=args.k, normalize=False)
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    port = {
+        "value": nq / med, "unit": "queries/s", "cores": int(threads), "kind": "port", "repeats": reps,
+        "best": nq / min(times),
+        "sample": f"{nq} of {args.queries} queries x full {x.shape[0]}x{x.shape[1]} index (fp32 up-cast of the stored "
+                  f"values), NumPy matmul + full argsort = oracle.inner_product (mips.py:552-560), median of {reps} runs "
+                  f"of {med:.2f} s; argsort is single-threaded, matmul uses {threads} BLAS threads; host has "
+                  f"{os.cpu_count()} logical cores",
+    }
+
+    ncpu = os.cpu_count() or 1
+    torch.set_num_threads(ncpu)
+    nqt = min(args.cpu_torch_queries, args.queries)
+    xt, qt = torch.from_numpy(x), torch.from_numpy(qa[:nqt])
+    orc.torch_topk(qt[:8], xt[:4096], args.k)
+    ttimes, tres = [], None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        tres = orc.torch_topk(qt, xt, args.k)
+        ttimes.append(time.perf_counter() - t0)
+    tmed = statistics.median(ttimes)
+    tor = {
+        "value": nqt / tmed, "unit": "queries/s", "cores": int(torch.get_num_threads()), "kind": "port", "repeats": reps,
+        "best": nqt / min(ttimes),
+        "sample": f"{nqt} of {args.queries} queries x full {x.shape[0]}x{x.shape[1]} index, torch.topk(q @ d.T, {args.k}) in "
+                  f"fp32 (retriever_lightning.py:304-305 idiom), 256-query chunks x <= 2^20-row blocks, running top-k "
+                  f"merge, median of {reps} runs of {tmed:.2f} s, torch threads = {torch.get_num_threads()} of "
+                  f"{ncpu} logical cores",
+    }
+    return port, tor, res, (tres[0].numpy(), tres[1].numpy())
+
+
+def regime(ram, torch, rows, d, nq, k, dtype, device, iters):
+    """One extra (index, Q) point measured in this same run: scan-kernel time from HIP events -> both roofline
+    fractions.  Used for the 2^24 x 768 index (BASELINE config 3's index on one GPU): Q = 4096 is the MFMA-bound
+    case at full size, Q = 8 the HBM-bound one -- the north star's literal 'fraction of the HBM-read roofline'."""
+    ix = ram.MipsIndex(d, dtype=dtype, device=device)
+    ix.reserve(rows)
+    ix.add_synthetic(rows, 0, ram.SEED_DOCS, ram.SYNTH_GAUSS)
+    out = []
+    esz = 1 if dtype != "bf16" else 2
+    for q_n, it in zip(nq, iters):
+        q = ram.synth_fill(q_n, d, 0, ram.SEED_QUERIES, ram.SYNTH_GAUSS, dtype="bf16", device=device)
+        for _ in range(2):
+            ix.search(q, k)
+        torch.cuda.synchronize()
+        ix.scan_timing(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(it):
+            ix.search(q, k)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / it
+        ix.check()
+        ms, cnt = ix.scan_timing()
+        scan = ms / max(1, cnt) * 1e-3
+        fl = 2.0 * q_n * rows * d
+        by = rows * d * float(esz) + q_n * d * float(esz) + q_n * k * 12.0
+        peak = PEAK_FP8_TFLOPS if esz == 1 else PEAK_BF16_TFLOPS
+        hbm_bound = (by / (PEAK_HBM_GBS * 1e9)) > (fl / (peak * 1e12))
+        out.append({
+            "workload": f"{rows}x{d} {dtype} index, Q={q_n}, k={k}", "queries_per_s": q_n / wall, "call_ms": wall * 1e3,
+            "kernel": ix.last_kernel, "kernel_ms": scan * 1e3, "launches_timed": cnt,
+            "bound": "hbm" if hbm_bound else "mfma",
+            "mfma_achieved_tflops": fl / scan / 1e12, "mfma_frac": fl / scan / (peak * 1e12),
+            "hbm_achieved_gbs": by / scan / 1e9, "hbm_frac": by / scan / (PEAK_HBM_GBS * 1e9),
+        })
+    del ix
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        raise SystemExit(self_launch(args))
+
     import torch
     import torch.distributed as dist
 
-    import retrieval_augmented_mds_amd as ram  # the timed path touches the product only; oracle/ is imported
-    # in cpu_baseline() alone
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    if args.launch_check:
+        # the N-rank launch path by itself: process group up, one collective, report (no GPU, no search)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo" if args.backend == "gloo" or not torch.cuda.is_available() else "nccl")
+            t = torch.tensor([rank + 1], dtype=torch.int64)
+            if dist.get_backend() == "nccl":
+                torch.cuda.set_device(local_rank)
+                t = t.cuda()
+            dist.all_reduce(t)
+            total = int(t.item())
+        else:
+            total = 1
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "world_size": dist.get_world_size() if world > 1 else 1,
+                              "backend": dist.get_backend() if world > 1 else None, "rank_sum": total,
+                              "self_launched": os.environ.get("MIPS_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    import retrieval_augmented_mds_amd as ram  # the timed path touches the product only; oracle/ is imported
+    # in cpu_baselines() alone
+
     if args.backend == "gloo":
         local_rank = 0  # rehearsal: every rank shares the one visible GPU
     torch.cuda.set_device(local_rank)
+    dist_info = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group("gloo")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+        rccl = None
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None
+        except Exception:
+            pass
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": rccl,
+                     "self_launched": os.environ.get("MIPS_BENCH_SELF_LAUNCHED") == "1"}
 
     n, d, nq, k = args.rows, args.dim, args.queries, args.k
     index = ram.ShardedMipsIndex(d, metric=ram.METRIC_IP, dtype=args.index_dtype, device=local_rank)
@@ -121,6 +257,16 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
+
+    coll_dev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
+    rows_per_gpu = [local_rows]
+    if world > 1:  # every rank's shard size, as the process group reports it
+        t = torch.zeros(world, dtype=torch.int64, device=coll_dev)
+        t[rank] = local_rows
+        dist.all_reduce(t)
+        rows_per_gpu = [int(v) for v in t.cpu().tolist()]
+        if sum(rows_per_gpu) != n:
+            raise SystemExit(f"shards cover {sum(rows_per_gpu)} of {n} rows")
 
     # N > 1 over RCCL: consecutive steps are independent query batches, so the exchange step of batch t (the ONE
     # all-gather + merge, on a side stream) overlaps the shard scan of batch t + 1 (ShardedMipsIndex.search_async).
@@ -144,7 +290,7 @@ def main():
         return out
 
     try:
-        run_steps(args.warmup)
+        run_steps(max(1, args.warmup))
         torch.cuda.synchronize()
     except Exception as e:  # the overlapped exchange is an optimisation: never let it cost the measurement
         if not pipelined:
@@ -152,12 +298,12 @@ def main():
         print(f"[bench] pipelined exchange failed on rank {rank} ({e!r}); using the synchronous path", file=sys.stderr, flush=True)
         pipelined = False
     if world > 1:  # all ranks must take the same path
-        flag = torch.tensor([1 if pipelined else 0], device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
+        flag = torch.tensor([1 if pipelined else 0], device=coll_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if pipelined and int(flag.item()) == 0:
             pipelined = False
         if not pipelined:
-            run_steps(args.warmup)
+            run_steps(max(1, args.warmup))
     torch.cuda.synchronize()
     barrier()
     index.local.scan_timing(reset=True)
@@ -167,8 +313,11 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    index.check()  # a scan kernel that gave up on its barrier poisons its results: never print a number over that
+    if bool((i == ram.IDX_POISON).any()):
+        raise SystemExit("the timed searches returned poisoned rows (scan kernel timeout on some rank)")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # every rank must hold the same global answer
@@ -184,8 +333,22 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = nq * args.steps / elapsed
 
+    # a second, untimed-for-`value` pass with one event pair per step: the distribution of step times
+    # (median and min).  Un-pipelined, so each sample is one complete step.
+    step_ms = []
+    if world == 1 or not pipelined:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a, b in evs:
+            a.record()
+            index.search(q_dev, k)
+            b.record()
+        torch.cuda.synchronize()
+        step_ms = [a.elapsed_time(b) for a, b in evs]
+    step_stats = {"median": statistics.median(step_ms), "min": min(step_ms), "max": max(step_ms), "samples": len(step_ms),
+                  "how": "one HIP event pair per step, separate pass after the timed region"} if step_ms else None
+
     # algorithmic work of ONE scan launch on this rank: flops = 2 Q N_local d,
-    # bytes = N_local d 2 (index, read once) + Q d 2 (queries) + Q k 12 (results)
+    # bytes = N_local d s (index, read once) + Q d s (queries) + Q k 12 (results)
     flops = 2.0 * nq * local_rows * d
     bytes_ = local_rows * d * float(esz) + nq * d * float(esz) + nq * k * 12.0
     ach_tflops = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
@@ -193,43 +356,61 @@ def main():
     # HBM-side traffic of one scan launch: PMC counters cannot be read from inside this process, so the
     # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/<round>/),
     # corrected as MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE counts wide reads at half: x2), and
-    # is only reported when that profile was taken on the same workload; otherwise null.
+    # is only reported when that profile was taken on the same workload AND the same kernel instance; otherwise null.
+    kernel_name = index.local.last_kernel
     traffic, traffic_src = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
             t = json.load(f)
-        if (t["rows_per_gpu"], t["dim"], t["queries"], t["k"], t.get("dtype", "bf16")) == (local_rows, d, nq, k, args.index_dtype):
+        same = (t["rows_per_gpu"], t["dim"], t["queries"], t["k"], t.get("dtype", "bf16")) == (local_rows, d, nq, k, args.index_dtype)
+        if same and t.get("kernel", kernel_name) == kernel_name:
             traffic = (2.0 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0
             traffic_src = t["source"]
     except Exception:
         pass
-    # the instance mips_search dispatches to for this shape (mips_hip.hip::launch_search); other shapes run
-    # other instances of the same kernels, named in the rocprofv3 summary of that run
-    if (d, k) == (768, 5) and nq > 256:
-        kernel_name = "mips::scan_kernel_f8x<6, 768, 2, 0>" if f8 else "mips::scan_kernel_v4<6, 24, 2, 0>"
-    else:
-        kernel_name = "mips::scan_kernel_f8x<...> / mips::scan_kernel_f8<...>" if f8 else "mips::scan_kernel_v3<...> / mips::scan_kernel<...> (see DESIGN.md section 4)"
+    # what a bare MFMA loop of the kernel's own operand mapping sustains on random data on this part
+    # (tools/mfma_ceiling.hip; committed measurement): the roof this kernel can actually approach
+    ceiling = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_ceiling.json")) as f:
+            c = json.load(f)
+        if not f8:
+            ceiling = c
+    except Exception:
+        pass
+    peak = PEAK_FP8_TFLOPS if f8 else PEAK_BF16_TFLOPS
     roofline = {
-        "bound": "mfma", "achieved": ach_tflops, "peak": PEAK_FP8_TFLOPS if f8 else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-        "frac": ach_tflops / (PEAK_FP8_TFLOPS if f8 else PEAK_BF16_TFLOPS), "traffic": traffic, "traffic_source": traffic_src,
-        "kernel": kernel_name,
-        "kernel_ms": scan_ms,
-        "launches_timed": scan_launches,
+        "bound": "mfma", "achieved": ach_tflops, "peak": peak, "unit": "TFLOP/s",
+        "frac": ach_tflops / peak, "traffic": traffic, "traffic_source": traffic_src,
+        "kernel": kernel_name, "kernel_ms": scan_ms, "launches_timed": scan_launches,
         "flops_per_launch": flops, "bytes_per_launch": bytes_,
         "hbm_achieved": ach_gbs, "hbm_peak": PEAK_HBM_GBS, "hbm_unit": "GB/s", "hbm_frac": ach_gbs / PEAK_HBM_GBS,
-        "note": "Q=4096 flop per index byte >> ~310 flop/B ridge: MFMA-bound; hbm_* = literal HBM-read fraction",
+        "note": "Q=4096 flop per index byte >> ~310 flop/B ridge: MFMA-bound; hbm_* = literal HBM-read fraction "
+                "(see `regimes` for the HBM-bound measurement)",
     }
+    if ceiling is not None:
+        roofline["ceiling_tflops"] = ceiling["bare_loop_tflops"]
+        roofline["ceiling_frac"] = ceiling["bare_loop_tflops"] / peak
+        roofline["frac_of_ceiling"] = ach_tflops / ceiling["bare_loop_tflops"]
+        roofline["ceiling_source"] = ceiling["source"]
 
-    cpu = None
+    cpu = cpu_t = None
     parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import numpy as np
 
-        cpu, (cs, ci) = cpu_baseline(index.local, q_dev, args)
-        gi = i[: ci.shape[0]].cpu().numpy()
-        gs = s[: ci.shape[0]].cpu().numpy()
-        parity = {"indices_equal_cpu_port": bool(np.array_equal(gi, ci)),
-                  "max_rel_score_diff": float(np.max(np.abs(gs - cs) / np.abs(cs)))}
+        cpu, cpu_t, (cs, ci), (ts, ti) = cpu_baselines(index.local, q_dev, args)
+        gi, gs = i.cpu().numpy(), s.cpu().numpy()
+        parity = {"indices_equal_cpu_port": bool(np.array_equal(gi[: ci.shape[0]], ci)),
+                  "max_rel_score_diff": float(np.max(np.abs(gs[: cs.shape[0]] - cs) / np.abs(cs))),
+                  "indices_equal_cpu_torch": bool(np.array_equal(gi[: ti.shape[0]], ti)),
+                  "max_rel_score_diff_torch": float(np.max(np.abs(gs[: ts.shape[0]] - ts) / np.abs(ts)))}
+
+    regimes = None
+    if rank == 0 and world == 1 and not args.no_regimes and not f8 and (n, d) == (1 << 20, 768):
+        free_b, _ = torch.cuda.mem_get_info()
+        if free_b > 40e9:
+            regimes = regime(ram, torch, 1 << 24, 768, [4096, 8], k, "bf16", local_rank, [5, 20])
 
     if rank == 0:
         out = {
@@ -242,8 +423,11 @@ def main():
                                    f"(config 5 with --index-dtype fp8_e4m3)",
                        "index_rows": n, "dim": d, "queries": nq, "k": k,
                        "parallelism": (f"row-sharded x{world} + 1 all-gather" + (", exchange of step t overlapped with the scan of step t+1" if pipelined else "")) if world > 1 else "single GPU",
-                       "rows_per_gpu": local_rows},
-            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_cpu_sample": parity,
+                       "rows_per_gpu": rows_per_gpu if world > 1 else local_rows},
+            "distributed": dist_info,
+            "step_ms": step_stats,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_torch": cpu_t, "parity_vs_cpu_sample": parity,
+            "regimes": regimes,
             "index_build_s": t_build,
         }
         print(json.dumps(out), flush=True)

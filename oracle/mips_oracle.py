@@ -408,3 +408,32 @@ def in_batch_scores(query_cls, mips_cls, normalize: bool = False):
     scores = query_cls @ mips_cls.T
     _, i = scores.topk(1)
     return scores, i.view(-1)
+
+
+# --------------------------------------------------------------------------
+# "reference CPU torch path"      the idiom of sotasum/retriever_lightning.py:304-305 scaled to [Q,d] x [N,d]^T
+# --------------------------------------------------------------------------
+def torch_topk(q, x, k: int, q_chunk: int = 256, x_block: int = 1 << 20):
+    """`scores = q @ x.T; scores.topk(k)` in fp32 on the host cores (torch threads as set by the caller).
+    [Q, N] fp32 would be 17 GB at BASELINE config 2, so it runs in q_chunk-query chunks over x_block-row document
+    blocks with a running top-k merge.  torch CPU tensors -> (scores [Q,k], indices [Q,k]
+    int64), descending."""
+    import torch
+
+    out_s, out_i = [], []
+    for q0 in range(0, q.shape[0], q_chunk):
+        qc = q[q0:q0 + q_chunk]
+        best_s = best_i = None
+        for x0 in range(0, x.shape[0], x_block):
+            sc = qc @ x[x0:x0 + x_block].T
+            s, i = sc.topk(min(k, sc.shape[1]), dim=1)
+            i = i + x0
+            if best_s is None:
+                best_s, best_i = s, i
+            else:
+                cs, ci = torch.cat((best_s, s), 1), torch.cat((best_i, i), 1)
+                best_s, sel = cs.topk(min(k, cs.shape[1]), dim=1)
+                best_i = torch.gather(ci, 1, sel)
+        out_s.append(best_s)
+        out_i.append(best_i)
+    return torch.cat(out_s), torch.cat(out_i)

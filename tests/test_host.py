@@ -288,4 +288,79 @@ def test_bench_defaults_are_the_baseline_headline_config(monkeypatch):
     tree = ast.parse(open(bench.__file__).read())
     for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
         imports_oracle = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
-        assert imports_oracle == (fn.name == "cpu_baseline"), fn.name
+        assert imports_oracle == (fn.name == "cpu_baselines"), fn.name
+
+
+def test_bench_gpus_n_launches_n_ranks_by_itself():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must produce a 2-rank run by itself: it
+    spawns a child torch.distributed.run of the same file BEFORE touching the GPU, relays its output and exits with
+    its code.  --launch-check forms the process group, exchanges one tensor and reports what was formed (the search
+    itself needs a GPU: -m gpu tests and the driver run it)."""
+    import json
+    import subprocess
+    import sys as _sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--launch-check"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line == {"launch_check": True, "n_gpus": 2, "world_size": 2, "backend": "gloo", "rank_sum": 3, "self_launched": True}
+    # a child that fails makes the parent fail (here: --gpus contradicts the WORLD_SIZE the launcher exports)
+    bad = subprocess.run([_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(29400 + os.getpid() % 500), os.path.join(root, "bench.py"), "--gpus", "3",
+                          "--launch-check"], capture_output=True, text=True, timeout=300, env=env)
+    assert bad.returncode != 0
+
+
+def test_oracle_torch_topk_and_eval_consumer_restatements():
+    import torch as _t
+
+    x = synth.generate(1, 0, 5000, 64, synth.KIND_GAUSS)
+    q = synth.generate(2, 0, 300, 64, synth.KIND_GAUSS)
+    s, i = orc.torch_topk(_t.from_numpy(q), _t.from_numpy(x), 5, q_chunk=128, x_block=1024)
+    es, ei = orc.search_exact(q, x, 5)
+    assert np.array_equal(i.numpy(), ei)
+    np.testing.assert_allclose(s.numpy(), es, rtol=1e-5)
+    # nearest_examples_batch drops ids < 0 like datasets/search.py
+    cols = {"aid": [f"a{t}" for t in range(3)]}
+    sc, ex = orc.nearest_examples_batch(lambda qq, kk: orc.search_exact_bruteforce(qq, x[:3], kk), cols, q[:2], 5)
+    assert [len(v) for v in sc] == [3, 3] and all(len(e["aid"]) == 3 for e in ex)
+    col, metric = orc.full_kb_eval_index(x, inner_product=False)
+    assert col.shape == (5000, 65) and metric == orc.METRIC_L2
+    np.testing.assert_allclose((col.astype(np.float64) ** 2).sum(1), float(orc.get_phi(x)), rtol=1e-5)
+
+
+def test_knowledge_base_add_faiss_index_argument_checks():
+    kb = ram.KnowledgeBase({"cls": np.zeros((4, 8), np.float32), "aid": list("abcd")})
+    with pytest.raises(NotImplementedError, match="Flat"):
+        kb.add_faiss_index("cls", string_factory="IVF16,Flat")
+    with pytest.raises(RuntimeError, match="no AMD GPU"):              # a legal build needs the GPU: no CPU fallback
+        kb.add_faiss_index("cls", metric_type=ram.METRIC_IP)
+    kb2 = ram.KnowledgeBase({"cls": synth.generate(1, 0, 6, 8, synth.KIND_GAUSS)})
+    with pytest.raises(NotImplementedError, match="phi-augmented"):
+        kb2.add_faiss_index("cls")                                      # metric None = faiss default L2, rows not augmented
+    fake = OracleIndex(synth.generate(1, 0, 6, 8, synth.KIND_GAUSS), 0)
+    kb2.add_faiss_index("cls", index_name="mine", custom_index=fake)    # HF's custom_index passthrough
+    assert kb2.get_index("mine").faiss_index is fake
+    s, e = kb2.get_nearest_examples_batch("mine", synth.generate(2, 0, 2, 8, synth.KIND_GAUSS), k=3)
+    assert len(s) == 2 and len(e[0]["cls"]) == 3
+
+
+def test_embedding_shard_files_roundtrip(tmp_path):
+    """encode_text2 / build_index() without arguments: the per-rank shard files (mips.py:243-244, 291-295)."""
+    n, d = 103, 16
+    emb = synth.generate(5, 0, n, d, synth.KIND_GAUSS)
+    data = {"mips_column": [f"text {t}" for t in range(n)], "aid": [f"a{t}" for t in range(n)]}
+    m = ram.Mips(ram.MipsArgs(mips_tmp_folder=str(tmp_path), mips_batch_size=10), data=data)
+    with pytest.raises(RuntimeError, match="encoder"):
+        m.encode_text2(0, 3)
+    m.encoder = lambda texts: emb[[int(t.split()[1]) for t in texts]]
+    for r in (2, 0, 1):                                                  # any order on disk
+        m.encode_text2(r, 3)
+    embs, cols = m._load_embedding_shards()
+    assert np.array_equal(np.concatenate(embs), emb) and cols == data    # rank order restored
+    empty = ram.Mips(ram.MipsArgs(mips_tmp_folder=str(tmp_path / "none")))
+    with pytest.raises(ValueError, match="no embedding shards"):
+        empty._load_embedding_shards()
