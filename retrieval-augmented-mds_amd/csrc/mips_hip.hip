@@ -17,6 +17,7 @@
 #include "scan_kernel_f8.hpp"
 #include "scan_kernel_f8x.hpp"
 #include "scan_kernel_v4.hpp"
+#include "scan_kernel_v5.hpp"
 
 namespace {
 
@@ -310,9 +311,13 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // higher clock pays: 4.54 vs 4.78 ms at BASELINE config 2); single-tile searches are HBM-bound and keep
     // scan_kernel_v3's non-temporal document DMA.  "variant" = 3 / 4 forces one of the two.
     const bool v4_shape = ix->ld % 128 == 0 && ix->ld >= 384 && ix->ld <= 768 && KL == 8 && ix->esize == 2 && ix->plane == 0;
+    // scan_kernel_v5 (64 stationary queries per wave, one wave per SIMD): row pitches whose 64-k slabs divide evenly
+    // among 4 waves
+    const bool v5_shape = (ix->ld == 768 || ix->ld == 512) && KL == 8 && ix->esize == 2 && ix->plane == 0;
+    const bool want_v5 = variant == 5 && v5_shape;
     const bool v4_forced = variant == 4 && v4_shape;
     const bool v4_auto = variant == 0 && ix->opt_sub == 0 && v4_shape;
-    if (variant != 1 && variant != 3) variant = 3;
+    if (variant != 1 && variant != 3) variant = 3; // (4 / 5 were decided above; the rest of the function only knows 1 and 3)
     const bool v3_dim = (ix->ld % 128 == 0 && ix->ld <= 768) || ix->ld == 1024;
     const bool v3_long = ix->ld == 256 || ix->ld == 512 || ix->ld == 768; // pitches with K' = 16 / 32 instances
     constexpr bool kl_short = KL <= 10; // K' = 8 / 10 lists fit the 8-wave (two per SIMD) configuration
@@ -336,8 +341,8 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     const int wg_target = variant == 1 ? 512 : 256;                   // resident workgroups on 256 CUs
     const int64_t nq_pad = round_up(nq, kQueryAlign);
     const int nqt = (int)((nq + tn - 1) / tn);
-    const bool want_v4 = v4_forced || (v4_auto && nqt > 1);
-    const int lists = (want_v4 || want_f8x) ? 4 : 2;                  // running lists per (query, split)
+    const bool want_v4 = !want_v5 && (v4_forced || (v4_auto && nqt > 1));
+    const int lists = (want_v4 || want_v5 || want_f8x) ? 4 : 2;                  // running lists per (query, split)
     const int ntiles = (int)((ix->ntotal + tm - 1) / tm);
     // Index splits (a multiple of 8: one XCD group each).  The grid nqt x nsplit should come in whole
     // "rounds" of wg_target resident workgroups: among the multiples of 8 up to 64 take the one whose last
@@ -379,7 +384,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
 #else
     const bool short_lists = false;
 #endif
-    const size_t ncand = (size_t)nsplit * lists * ((want_v4 || want_f8x || short_lists) ? V4_KLL : KL);
+    const size_t ncand = (size_t)nsplit * lists * ((want_v4 || want_v5 || want_f8x || short_lists) ? V4_KLL : KL);
     int rc = ix->part_s.ensure((size_t)nq_pad * ncand * sizeof(float));
     if (rc) return rc;
     rc = ix->part_i.ensure((size_t)nq_pad * ncand * sizeof(int));
@@ -416,7 +421,22 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
 
     const int grid = qt_per_group * qgroups * nsplit;
     const int slot = ix->ev_next;
-    if (want_v4) {
+    if (want_v5) {
+        if constexpr (KL == 8) {
+            const int lds = 3 * mips::V3_DB * ix->ld * 2 + 4 * 2048 + 1024 + 16; // ring + threshold words + dump area + arrival counter
+            auto go5 = [&](auto kern) -> int {
+                HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                if (ix->timing_armed) HIP_TRY(hipEventRecord(ix->ev0[slot], st));
+                kern<<<grid, 256, lds, st>>>(a);
+                return MIPS_OK;
+            };
+            int rc2;
+            if (ix->ld == 768) rc2 = go5(mips::scan_kernel_v5<V4_KLL, 24>);
+            else rc2 = go5(mips::scan_kernel_v5<V4_KLL, 16>);
+            if (rc2) return rc2;
+            set_kernel_name(ix, "mips::scan_kernel_v5<%d, %d, 2, 0>", V4_KLL, ix->ld / 32);
+        }
+    } else if (want_v4) {
         if constexpr (KL == 8) {
             const int lds = 3 * mips::V3_DB * ix->ld * 2 + 8 * 1024 + 1024 + 16; // ring + threshold words + dump area + arrival counter
             auto go4 = [&](auto kern) -> int {

