@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--cpu-queries", type=int, default=256, help="queries per repeat of the NumPy-port CPU baseline")
-    ap.add_argument("--cpu-torch-queries", type=int, default=1024, help="queries per repeat of the torch CPU baseline")
+    ap.add_argument("--cpu-torch-queries", type=int, default=512, help="queries per repeat of the torch CPU baseline")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-regimes", action="store_true", help="skip the 2^24-row regime measurements (N = 1 only)")
