@@ -48,6 +48,13 @@ def _stale() -> bool:
     return any(os.path.getmtime(s) > t for s in _sources())
 
 
+# -amdgpu-mfma-vgpr-form: MFMA results in architectural VGPRs even in kernels that pin values in AGPRs.  The
+# query-stationary kernels fill the AGPR half of the register file with stationary B fragments (inline-asm "a"
+# constraints); without the option LLVM then selects the AGPR-destination MFMA forms for the whole kernel, the
+# accumulators compete with the fragments for AGPRs and scan_kernel_v5 spills fragments (reloaded behind a vmcnt(0)
+# that drains the LDS-DMA ring); with it: 254 VGPRs + 256 AGPRs, no scratch.  No other kernel changes its spill count.
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+
 EXP_LIB_PATH = os.path.join(_ROOT, "tools", "_build", "libmips_hip_exp.so")
 
 
@@ -59,8 +66,7 @@ def build_experimental(verbose: bool = False) -> str:
     os.makedirs(os.path.dirname(EXP_LIB_PATH), exist_ok=True)
     if os.path.exists(EXP_LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(EXP_LIB_PATH) for s in _sources()):
         return EXP_LIB_PATH
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DMIPS_EXPERIMENTAL",
-           "-o", EXP_LIB_PATH, os.path.join(CSRC, "mips_hip.hip")]
+    cmd = [hipcc, *HIPCC_FLAGS, "-DMIPS_EXPERIMENTAL", "-o", EXP_LIB_PATH, os.path.join(CSRC, "mips_hip.hip")]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)
@@ -86,8 +92,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             if not force and not _stale():  # another process built it while we waited
                 return LIB_PATH
             tmp = LIB_PATH + f".tmp{os.getpid()}"
-            cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-                   "-o", tmp, os.path.join(CSRC, "mips_hip.hip")]
+            cmd = [hipcc, *HIPCC_FLAGS, "-o", tmp, os.path.join(CSRC, "mips_hip.hip")]
             if verbose:
                 print(" ".join(cmd), flush=True)
             proc = subprocess.run(cmd, capture_output=True, text=True)

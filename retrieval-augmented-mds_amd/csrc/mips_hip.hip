@@ -431,6 +431,12 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
                 return MIPS_OK;
             };
             int rc2;
+#ifdef MIPS_EXPERIMENTAL
+            if (ix->ld == 768 && ix->opt_sub == 8) rc2 = go5(mips::scan_kernel_v5<V4_KLL, 24, 2, 1>); // timing only: no epilogue
+            else if (ix->ld == 768 && ix->opt_sub == 21) rc2 = go5(mips::scan_kernel_v5<V4_KLL, 24, 3>); // prefetch depth 3
+            else if (ix->ld == 768 && ix->opt_sub == 22) rc2 = go5(mips::scan_kernel_v5<V4_KLL, 24, 4>); // prefetch depth 4
+            else
+#endif
             if (ix->ld == 768) rc2 = go5(mips::scan_kernel_v5<V4_KLL, 24>);
             else rc2 = go5(mips::scan_kernel_v5<V4_KLL, 16>);
             if (rc2) return rc2;

@@ -23,11 +23,26 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "scan_kernel.hpp"
 #include "scan_kernel_v3.hpp"
 #include "scan_kernel_v4.hpp"
 
 namespace mips {
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), every call inlined.  hipcc
+// declines to fully unroll a `#pragma unroll` loop of the size of a chain step sequence (and a loop left rolled turns
+// the fragment-register indices into scratch accesses).
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 template <int KL, int KS32, int AD = 2, int TIMING_MODE = 0>
 __global__ __launch_bounds__(256, 1) void scan_kernel_v5(ScanArgs p) {
@@ -47,7 +62,7 @@ __global__ __launch_bounds__(256, 1) void scan_kernel_v5(ScanArgs p) {
     static_assert(PPW == 4 * SPW, "pieces per wave");
     static_assert(AD >= 1 && AD < OWN, "the ring's first AD positions of a block must be own slabs, with a step left for the poll");
     constexpr int NFRAG = NQB * KS32;
-    constexpr int NFRAG_A = NFRAG > 60 ? 60 : NFRAG / 2; // stationary fragments pinned in AGPRs (<= 240 of the 256)
+    constexpr int NFRAG_A = NFRAG > 64 ? 64 : NFRAG / 2; // stationary fragments pinned in AGPRs (240 registers; the accumulators take the other 16)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -73,22 +88,29 @@ __global__ __launch_bounds__(256, 1) void scan_kernel_v5(ScanArgs p) {
 
     // ---- stationary query fragments, in the wave's k-order: lane holds Q[q0 + 16 n + c][32 s + 8 g .. +8)
     bf16x8 bq[NQB][KS32];
+    // loaded in batches of 12 fragments, each batch pinned before the next is requested: left alone, hipcc issues all
+    // 96 loads first (384 transient VGPRs), spills fragments in the prologue and reloads them -- behind a vmcnt(0) that
+    // drains the LDS-DMA ring -- in every block
 #pragma unroll
     for (int n = 0; n < NQB; ++n) {
         const uint16_t* qrow = p.qbuf + ((int64_t)qt * TN + wave * 64 + n * 16 + c) * p.ld + 8 * g;
 #pragma unroll
-        for (int j = 0; j < KS32; ++j) {
-            int s = rot + j;
-            if (s >= KS32) s -= KS32;
-            bq[n][j] = *reinterpret_cast<const bf16x8*>(qrow + 32 * s);
-        }
+        for (int jb = 0; jb < KS32; jb += 12) {
+#pragma unroll
+            for (int j = jb; j < jb + 12 && j < KS32; ++j) {
+                int s = rot + j;
+                if (s >= KS32) s -= KS32;
+                bq[n][j] = *reinterpret_cast<const bf16x8*>(qrow + 32 * s);
+            }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-        for (int j = 0; j < KS32; ++j) {
-            if (n * KS32 + j < NFRAG_A) asm volatile("" : "+a"(bq[n][j]));
-            else asm volatile("" : "+v"(bq[n][j]));
-        }
+            for (int j = jb; j < jb + 12 && j < KS32; ++j) {
+                if (n * KS32 + j < NFRAG_A) asm volatile("" : "+a"(bq[n][j]) : : "memory");
+                else asm volatile("" : "+v"(bq[n][j]) : : "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #endif
+        }
     }
 
     float ls[NQB][KL];
@@ -118,29 +140,29 @@ __global__ __launch_bounds__(256, 1) void scan_kernel_v5(ScanArgs p) {
     const __amdgpu_buffer_rsrc_t thr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(reinterpret_cast<unsigned char*>(p.gthr) + (int64_t)qt * (WAVES * THR_WAVE) - (int64_t)THR_AREA), 0,
         (int)(THR_AREA + WAVES * THR_WAVE), 0x00020000);
-    auto refresh_thresholds = [&](bool real) { // !real: out-of-range dummies into the dump area (uniform vmcnt count)
+    auto refresh_thresholds = [&]() { // two 1-KiB pieces; blocks that do not refresh issue nothing (their counted wait differs)
         const unsigned voff = thr_base_of() + lane_id_here() * 16u;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            lds_void* dst = (lds_void*)(smem + (real ? thr_base_of() + 1024u * h : DUMP_AREA));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rsrc, dst, 16, real ? voff + 1024u * h : (voff | 0x40000000u), 0, 0, 16);
-        }
+        for (int h = 0; h < 2; ++h)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rsrc, (lds_void*)(smem + thr_base_of() + 1024u * h), 16, voff + 1024u * h, 0, 0, 16);
     };
 
     // ---- LDS-DMA map: piece (slab, rg) = rows 8 rg .. 8 rg + 7 of 64-k slab `slab`, at stage + (4 slab + rg) KiB;
     // wave w brings slabs SPW w .. SPW w + SPW - 1 (all four row groups): its i-th piece is slab SPW w + (i >> 2), rg i & 3
     const unsigned char* docs_b = reinterpret_cast<const unsigned char*>(p.docs);
     const int64_t row_bytes = (int64_t)p.ld * 2;
+    // The lane part of the source address lives in two persistent VGPRs (even / odd row groups): with one wave per
+    // SIMD every instruction of a piece is MFMA issue time, and re-deriving it per piece (scan_kernel_v4 does, it has
+    // no register to spare and a SIMD partner to hide behind) costs ~5 dependent VALU operations x 14 pieces a block
+    const unsigned lane_off0 = (unsigned)(lane >> 3) * (unsigned)row_bytes + ((((unsigned)lane & 7u) ^ (((unsigned)lane >> 4) & 7u)) << 4);
+    const unsigned lane_off1 = lane_off0 ^ 64u;
     auto issue_piece = [&](const unsigned char* blk_base, int stage, int i) {
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void*)blk_base, 0, (int)(V3_DB * row_bytes), 0x00020000);
         const int slab = SPW * wave + (i >> 2), rg = i & 3;
         const int pc = slab * 4 + rg;
-        const unsigned ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        const unsigned lane_off0 = (ln >> 3) * (unsigned)row_bytes + (((ln & 7u) ^ ((ln >> 4) & 7u)) << 4);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + stage * STAGE_BYTES + pc * 1024), 16,
-                                                 (rg & 1) ? (lane_off0 ^ 64u) : lane_off0,
-                                                 rg * 8 * (int)row_bytes + slab * 128, 0, 0);
+                                                 (rg & 1) ? lane_off1 : lane_off0, rg * 8 * (int)row_bytes + slab * 128, 0, 0);
     };
 
     // ---- A-fragment read: row 16 half + c, chunk 4 (s & 1) + g of slab s >> 1, slot chunk ^ ((row >> 1) & 7)
@@ -181,32 +203,34 @@ __global__ __launch_bounds__(256, 1) void scan_kernel_v5(ScanArgs p) {
         }
     };
 
-    // ---- top-K epilogue of ONE query block n of a 16-document half: acc = documents base .. base + 3 against query
-    // 16 n + c.  Fast path: 2 max, 1 compare, one branch.
-    auto epilogue_n = [&](const f32x4& a, int n, int blk, int half, bool ragged) {
+    // ---- top-K epilogue of ONE query block n of a 16-document half: a = documents base .. base + 3 against query
+    // 16 n + c.  Fast path: 2 max, 1 compare and one NOT-TAKEN branch (the insert code is laid out out of line:
+    // with one wave per SIMD a taken branch is an instruction-fetch bubble in the MFMA stream; the first version of
+    // this kernel, whose fast path jumped over the insert code 8 times per block and tested `ragged` separately, lost
+    // 17 % to its epilogue where scan_kernel_v4 loses 5 %).
+    auto epilogue_n = [&](const f32x4& a, int n, int blk, int half, bool ragged) __attribute__((always_inline)) {
         if (TIMING_MODE == 1) {
 #if defined(__HIP_DEVICE_COMPILE__)
             asm volatile("" ::"v"(a));
 #endif
             return;
         }
-        f32x4 v = a;
-        if (ragged) { // last block of the index only (uniform)
-            const int base = blk * V3_DB + 16 * half + 4 * (int)(lane_id_here() >> 4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if ((int64_t)(base + r) >= p.ntotal) v[r] = -INFINITY;
-        }
-        const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-        if (__ballot(mx > thr[n]) != 0ull) {
+        const float mx = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+        if (__builtin_expect(ragged || __ballot(mx > thr[n]) != 0ull, 0)) {
             const unsigned ln = lane_id_here();
             const int base = blk * V3_DB + 16 * half + 4 * (int)(ln >> 4);
+            f32x4 v = a;
+            if (ragged) { // last block of the index only (uniform)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if ((int64_t)(base + r) >= p.ntotal) v[r] = -INFINITY;
+            }
             const float mark = ls[n][0];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float s = v[r];
-                if (s > thr[n]) {
-                    list_insert<KL>(ls[n], li[n], s, base + r);
+                const float sc = v[r];
+                if (sc > thr[n]) {
+                    list_insert<KL>(ls[n], li[n], sc, base + r);
                     thr[n] = fmaxf(thr[n], ls[n][KL - 1]);
                 }
             }
@@ -241,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void scan_kernel_v5(ScanArgs p) {
     if (nb > 0) {
 #pragma unroll
         for (int a = 0; a < AHEAD; ++a) { // same operation sequence as steady-state blocks (vmcnt arithmetic)
-            refresh_thresholds(true);
+            refresh_thresholds();
 #pragma unroll
             for (int i = 0; i < PPW; ++i) issue_piece(a < nb ? first + a * blk_bytes : last, a, i);
         }
@@ -256,6 +280,9 @@ __global__ __launch_bounds__(256, 1) void scan_kernel_v5(ScanArgs p) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_BLOCK) : "memory");
         arrive();
 
+        // ONE accumulator set (a second one does not fit: 384 fragment registers + lists leave ~28 registers for
+        // everything else, hipcc spills fragments and reloads them behind vmcnt(0)): the pre-test of query block n sits
+        // right before the chain-start MFMA that overwrites acc[n] (C = 0), under the MFMAs of the other query blocks
         f32x4 acc[NQB];
 #pragma unroll
         for (int n = 0; n < NQB; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -272,9 +299,10 @@ __global__ __launch_bounds__(256, 1) void scan_kernel_v5(ScanArgs p) {
         // half 0 at chain positions OWN + 1, OWN + 4, ... , half 1 spread evenly, the last one before position KS32 - 3
         constexpr int P0 = PPW / 2, P1 = PPW - P0;
         constexpr int STRIDE0 = (KS32 - OWN - 1) / P0 > 0 ? (KS32 - OWN - 1) / P0 : 1;
-        constexpr int STRIDE1 = (KS32 - 3) / P1 > 0 ? (KS32 - 3) / P1 : 1;
+        constexpr int LASTJ = KS32 - AD - 1; // chain position of half 1 after which the ring reads the NEXT block
+        constexpr int STRIDE1 = LASTJ / P1 > 0 ? LASTJ / P1 : 1;
         static_assert(OWN + 1 + (P0 - 1) * STRIDE0 < KS32, "half-0 piece schedule");
-        static_assert((P1 - 1) * STRIDE1 < KS32 - 3, "half-1 piece schedule: all pieces before the counted wait");
+        static_assert((P1 - 1) * STRIDE1 < LASTJ, "half-1 piece schedule: all pieces before the counted wait");
 
         for (int i = 0; i < nb; ++i) {
             const int blk = b0 + i;
@@ -282,18 +310,19 @@ __global__ __launch_bounds__(256, 1) void scan_kernel_v5(ScanArgs p) {
             const int nstage = stage == STAGES - 1 ? 0 : stage + 1;
             const bool ragged = (int64_t)(blk + 1) * V3_DB > p.ntotal;       // uniform
             const bool pragged = (int64_t)blk * V3_DB > p.ntotal;           // the pending block (blk - 1) is ragged
-            refresh_thresholds(refresh); // first VMEM operations of the block
+            if (refresh) refresh_thresholds(); // first VMEM operations of the block
             if (pend_blk >= 0 && pend_refresh && TIMING_MODE == 0) apply_bounds();
             const int rd0 = rd0_of(lane_id_here());
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                for (int j = 0; j < KS32; ++j) {
-                    const int t = half * KS32 + j;
+            // one 16-document half; HALF is a compile-time constant (two explicit instantiations: hipcc does not
+            // unroll a loop over the halves around a body of this size, and a runtime `half` would turn the
+            // fragment-register indices into scratch accesses)
+            auto chain = [&](auto half_c) {
+                constexpr int half = decltype(half_c)::value;
+                static_for<KS32>([&](auto j_c) __attribute__((always_inline)) {
+                    constexpr int j = decltype(j_c)::value;
+                    constexpr int t = half * KS32 + j;
                     if (j == 0) {
-                        // chain start: the pre-test of query block n sits right before the MFMA that overwrites acc[n],
-                        // under the MFMAs of the other query blocks
 #pragma unroll
                         for (int n = 0; n < NQB; ++n) {
                             if (half == 1) epilogue_n(acc[n], n, blk, 0, ragged);
@@ -318,14 +347,17 @@ __global__ __launch_bounds__(256, 1) void scan_kernel_v5(ScanArgs p) {
                     if (half == 0 && j > OWN && (j - OWN - 1) % STRIDE0 == 0 && (j - OWN - 1) / STRIDE0 < P0)
                         issue_piece(pbase, pstage, (j - OWN - 1) / STRIDE0);
                     if (half == 1 && j % STRIDE1 == 0 && j / STRIDE1 < P1) issue_piece(pbase, pstage, P0 + j / STRIDE1);
-                    if (half == 1 && j == KS32 - 3) {
+                    if (half == 1 && j == LASTJ) {
                         // before the ring crosses into the next block: this wave's share of it has landed (everything
-                        // but this block's own operations)
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_BLOCK) : "memory");
+                        // but this block's own operations: its pieces, and two more in a block that refreshed)
+                        if (refresh) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 2) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+                });
+            };
+            chain(std::integral_constant<int, 0>{});
+            chain(std::integral_constant<int, 1>{});
             arrive(); // all LDS reads of this block are issued and consumed; the second half's epilogue runs later
             pend_blk = blk;
             pend_refresh = refresh;

@@ -918,7 +918,8 @@ def test_experimental_scan_variants_are_bit_identical():
     es, ei = orc.search_exact(q.float().cpu().numpy()[:64], x, k)
     assert np.array_equal(ref_i[:64].cpu().numpy(), ei) and np.array_equal(ref_s[:64].cpu().numpy(), es)
     for params in ({"variant": 4}, {"variant": 3}, {"variant": 1}, {"variant": 3, "nsplit": 40}, {"variant": 3, "qgroups": 2},
-                   {"variant": 4, "nsplit": 8}, {"variant": 4, "qgroups": 4}):
+                   {"variant": 4, "nsplit": 8}, {"variant": 4, "qgroups": 4},
+                   {"variant": 5}, {"variant": 5, "nsplit": 8}, {"variant": 5, "nsplit": 40}):   # 5 = 64 stationary queries per wave
         for name in ("variant", "nsplit", "qgroups"):
             ix.set_param(name, params.get(name, 0))
         s, i = ix.search(q, k)
