@@ -212,6 +212,8 @@ int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out
  * to a multiple of 8), "qgroups" = query-tile groups per XCD octet (1, 2, 4 or 8), "variant" = scan kernel (1 = 128x128
  * register-staged tiles, 3 = query-stationary on the 32x32x16 MFMA shape, 4 = query-stationary on the
  * 16x16x32 shape (d padding to 384 .. 768, k <= 5)).  Results never depend on these four; only speed does.
+ * "margin_check" (0 / 1 / 2) selects what happens to queries whose candidate pool is not provably wide enough: see
+ * mips_index_margin_stats.
  * Two more names exist for tests and experiments and are NOT tuning knobs:
  *   "spin_limit"  polls a wave spends on the scan's block barrier before it gives up (0 = the shipped 2^22).  A tiny
  *                 value makes the kernel give up spuriously and -1 makes every scan launch raise its error word
@@ -231,6 +233,25 @@ int mips_index_set_param(mips_index_t* index, const char* name, int64_t value);
  * writes to HOST buffers, after its own synchronisation.  Nothing in the reference corresponds (faiss IndexFlat
  * cannot fail this way). */
 int mips_index_check_error(mips_index_t* index, int synchronize, void* hip_stream);
+
+/* Margin check -- is "exact" certified for this query?  The MFMA scores (fp32 accumulation) only select a candidate
+ * pool that is then re-scored exactly; a true top-k document can be missing from the pool only if enough others score
+ * within the MFMA rounding error of it.  Every search therefore compares, per query, the exact k-th score tk with the
+ * best MFMA score B anything OUTSIDE the pool can have had (unpopped list entries, documents rejected by an insert
+ * bound, documents dropped from a full running list) and FLAGS the query when B + e >= tk, e = d 2^-23 |q| max|x|
+ * (a rigorous bound for fp32 accumulation of the exact bf16 / e4m3 products).  "margin_check" (mips_index_set_param):
+ *   0  off;
+ *   1  (default) flag and count on the device -- nothing synchronises; read the count with this call;
+ *   2  certify: mips_search synchronises and re-scans the flagged queries with the widest lists (K' = 32; 16 on an
+ *      fp8 index), overwriting their rows.  Searches into HOST buffers synchronise anyway and always do this unless
+ *      the check is off.
+ * Outputs of the LAST search on the index: flagged = queries flagged by the first pass (-1: only counted on the
+ * device and synchronize == 0), rescanned = queries re-scanned, unresolved = queries still flagged afterwards (their
+ * results are the best this build can do; on tie-free data they are exact in practice -- the MFMA error observed is
+ * ~sqrt(d) 2^-24, two orders of magnitude below the bound).  Nothing in the reference corresponds (faiss IndexFlat
+ * computes its scores in fp32 as well and offers no certificate). */
+int mips_index_margin_stats(mips_index_t* index, int64_t* flagged, int64_t* rescanned, int64_t* unresolved,
+                            int synchronize, void* hip_stream);
 
 /* Name of the scan-kernel instance the last mips_search on this index dispatched to, in the form rocprofv3 prints
  * it (e.g. "mips::scan_kernel_v4<6, 24, 2, 0>"); "" before the first search.  bench.py's roofline.kernel. */

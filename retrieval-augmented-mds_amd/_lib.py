@@ -136,6 +136,7 @@ def _bind(lib):
         "mips_scan_timing": (i32, [vp, c.POINTER(c.c_float), c.POINTER(c.c_int), i32]),
         "mips_index_check_error": (i32, [vp, i32, vp]),
         "mips_index_last_kernel": (c.c_char_p, [vp]),
+        "mips_index_margin_stats": (i32, [vp, c.POINTER(i64), c.POINTER(i64), c.POINTER(i64), i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
@@ -150,7 +151,7 @@ EXPORTS = (
     "mips_index_dim", "mips_index_metric", "mips_index_phi", "mips_index_set_phi", "mips_index_read_rows",
     "mips_index_add_synthetic", "mips_synth_fill", "mips_search", "mips_merge_topk",
     "mips_merge_topk_packed", "mips_filter_ignore", "mips_cosine_rescore", "mips_cosine_rescore_bias", "mips_l2_normalize", "mips_rows_max_sumsq", "mips_index_set_param", "mips_scan_timing",
-    "mips_index_check_error", "mips_index_last_kernel", "mips_cosine_rescore_backward",
+    "mips_index_check_error", "mips_index_last_kernel", "mips_cosine_rescore_backward", "mips_index_margin_stats",
 )
 
 

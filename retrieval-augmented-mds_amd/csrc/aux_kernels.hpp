@@ -363,6 +363,13 @@ struct MergeArgs {
     int64_t* out_packed; // optional [nq][k][2] = {float bits (zero-extended), global id}: the all-gather payload
     const unsigned* err; // the scan kernel's error word of this call (nullptr: the generic kernel has no bounded spin)
     unsigned* sticky;    // host-visible (pinned, mapped) word of the index: set to 1 when `err` was set
+    // ---- margin check: is the candidate pool provably wide enough?
+    int ll;               // entries per running list of the scan kernel (6 for the 16x16 kernels, K' otherwise)
+    float* bnd;           // [nq] out of merge_select: no document OUTSIDE the pool has an MFMA score above this
+    unsigned char* flag;  // [nq] out of the re-score: 1 = the k-th exact score is within the MFMA error of bnd
+    unsigned* nflag;      // device counter of flagged queries of this call (nullptr: margin check off)
+    const double* xmax2;  // device scalar: max_i |x_i|^2 over the stored rows
+    double err_c;         // MFMA score error <= err_c * |q| * |x|   (d * 2^-23: fp32 accumulation of exact products)
 };
 
 // What a search whose scan kernel gave up (split-barrier spin bound, scan_kernel_v3.hpp) returns instead of
@@ -398,12 +405,17 @@ __global__ __launch_bounds__(64) void merge_select_kernel(MergeArgs p, int* cand
         ls[i] = -INFINITY;
         li[i] = IDX_NONE;
     }
+    // lb: the best score a document DROPPED from a full running list can have had = that list's last entry
+    float lb = -INFINITY;
     for (int c = lane; c < p.ncand; c += 64) {
         const float s = ps[c];
         const int id = pi[c];
         if (ranks_before(s, id, ls[KL - 1], li[KL - 1])) list_insert_full<KL>(ls, li, s, id);
+        if (id != IDX_NONE && (c % p.ll) == p.ll - 1) lb = fmaxf(lb, s);
     }
     int ci = IDX_NONE;
+    float last_pop = -INFINITY;
+    int pops = 0;
     for (int r = 0; r < KL; ++r) {
         const float hs = ls[0];
         const int hi = li[0];
@@ -428,8 +440,21 @@ __global__ __launch_bounds__(64) void merge_select_kernel(MergeArgs p, int* cand
             li[KL - 1] = IDX_NONE;
         }
         if (lane == r) ci = bi;
+        if (bi != IDX_NONE) {
+            last_pop = bs;
+            ++pops;
+        }
     }
     if (lane < KL) cand[(size_t)q * KL + lane] = ci;
+    if (p.bnd != nullptr) {
+        // Every document outside the pool has an MFMA score <= bnd: list entries that were not popped rank behind
+        // the pool's last member; documents rejected by a shared insert bound g scored below g <= the K'-th best
+        // list entry (g is vouched for by K' list entries); documents dropped from a full list scored <= its last
+        // entry.  A pool that is not full (fewer than K' entries anywhere) excluded nothing by rank.
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lb = fmaxf(lb, __shfl_xor(lb, off));
+        if (lane == 0) p.bnd[q] = fmaxf(pops == KL ? last_pop : -INFINITY, lb);
+    }
 }
 
 template <int KL, typename EL, bool L2>
@@ -481,7 +506,7 @@ __global__ __launch_bounds__(64) void rescore_rank_kernel(MergeArgs p, const int
                         const double xe = (double)EL::get(xv, e);
                         const double ye = (double)EL::get(yv, e);
                         dot += xe * ye;
-                        if (L2) qq += ye * ye; // |q|^2 is only needed for the L2 distances
+                        qq += ye * ye; // |q|^2: L2 distances and the margin check
                     }
                 }
             }
@@ -507,6 +532,37 @@ __global__ __launch_bounds__(64) void rescore_rank_kernel(MergeArgs p, const int
         if (oi != IDX_NONE) {
             ++nvalid;
             if (ranks_before(ok, oi, key, ci)) ++rank;
+        }
+    }
+    if (p.nflag != nullptr) {
+        // Margin check.  tk = exact inner product of the k-th result; a document outside the pool has an exact
+        // inner product <= bnd + e, e = err_c |q| max|x|.  If that can reach tk the pool was not provably wide
+        // enough: flag the query (the host re-scans flagged queries with the widest lists, mips_hip.hip).
+        double tk = 0.0, qn = 0.0;
+        bool have = false;
+#pragma unroll
+        for (int jj = 0; jj < KL; ++jj) {
+            const int orank = __shfl(rank, gbase + jj);
+            const int oi = __shfl(ci, gbase + jj);
+            const double od = __shfl(dot, gbase + jj);
+            const double oq = __shfl(qq, gbase + jj);
+            if (oi != IDX_NONE) {
+                qn = oq;
+                if (orank == p.k - 1) {
+                    tk = od;
+                    have = true;
+                }
+            }
+        }
+        if (inq && slot == 0) {
+            const float b = p.bnd[q];
+            bool fl = false;
+            if (have && b > -INFINITY) {
+                const double e = p.err_c * sqrt(qn) * sqrt(*p.xmax2);
+                fl = !((double)b + e < tk); // also true for NaN: never certify what cannot be compared
+            }
+            p.flag[q] = fl ? 1 : 0;
+            if (fl) atomicAdd(p.nflag, 1u);
         }
     }
     if (!inq) return;
@@ -712,6 +768,32 @@ __global__ __launch_bounds__(256) void cosine_rescore_bwd_kernel(const T* query,
         }
         g_query[b * d + t] = gq;
     }
+}
+
+// ------------------------------------------------------------------ re-scan of flagged queries: gather / scatter
+// gather staged query rows (row_bytes each, a multiple of 16) ids[t] -> row t; rows n .. n_out - 1 are zeroed
+__global__ void gather_rows_kernel(const unsigned char* src, const int* ids, int64_t n, int64_t n_out, int row_bytes, unsigned char* dst) {
+    const int chunks = row_bytes / 16;
+    const int64_t total = n_out * chunks;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / chunks;
+        const int c = (int)(t % chunks);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < n) v = *reinterpret_cast<const u32x4*>(src + (size_t)ids[row] * row_bytes + (size_t)c * 16);
+        *reinterpret_cast<u32x4*>(dst + (size_t)row * row_bytes + (size_t)c * 16) = v;
+    }
+}
+// scatter result rows back: row t of the compact results -> row ids[t]; `words` 8-byte words per row (k for the
+// index array or the packed payload's 2 k; the float scores go through scatter_f32)
+__global__ void scatter_i64_kernel(const int64_t* src, const int* ids, int64_t n, int words, int64_t* dst) {
+    const int64_t total = n * words;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
+        dst[(size_t)ids[t / words] * words + t % words] = src[t];
+}
+__global__ void scatter_f32_kernel(const float* src, const int* ids, int64_t n, int words, float* dst) {
+    const int64_t total = n * words;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
+        dst[(size_t)ids[t / words] * words + t % words] = src[t];
 }
 
 __global__ void fill_empty_kernel(float* out_s, int64_t* out_i, int64_t* out_packed, int64_t total, int metric) {

@@ -121,6 +121,17 @@ struct mips_index {
     unsigned* sticky_host = nullptr;
     unsigned* sticky_dev = nullptr;
     char last_kernel[96] = ""; // instance mips_search dispatched last (mips_index_last_kernel)
+    // margin check.  0 = off, 1 = flag and count on the device (never synchronises), 2 = certify:
+    // synchronise, re-scan the flagged queries with the widest lists.  Host-output searches always certify (they
+    // synchronise anyway) unless the check is off.
+    int opt_margin = 1;
+    Buffer mbnd, mflag, qbuf2, qf32b, tmp_s, tmp_i, ids;
+    double* xmax2_dev = nullptr; // max_i |x_i|^2 of the LOCAL rows, on the device (no host copy: never synchronises)
+    bool xmax2_valid = false;
+    unsigned* nflag_host = nullptr; // pinned: flagged-query count of the last certified search
+    int64_t last_flagged = -1, last_rescanned = 0, last_unresolved = 0;
+    int rescan_depth = 0;
+    unsigned* last_nflag_dev = nullptr;
     int opt_variant = 0; // 0 = automatic, 1 = scan_kernel (128x128 tiles), 3 = scan_kernel_v3 (32x32x16), 4 = scan_kernel_v4 (16x16x32)
     hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
     int ev_count = 0; // pairs recorded since the last reset (saturates at kEvRing)
@@ -296,6 +307,23 @@ int compute_phi(mips_index* ix, hipStream_t st) {
     HIP_TRY(hipStreamSynchronize(st));
     std::memcpy(&ix->phi, &bits, 8);
     ix->phi_valid = true;
+    return MIPS_OK;
+}
+
+// max_i |x_i|^2 of the local rows into a device scalar, stream-ordered, no host copy (the margin check's error bound)
+int ensure_xmax2(mips_index* ix, hipStream_t st) {
+    if (ix->xmax2_valid) return MIPS_OK;
+    if (!ix->xmax2_dev) HIP_TRY(hipMalloc((void**)&ix->xmax2_dev, 8));
+    HIP_TRY(hipMemsetAsync(ix->xmax2_dev, 0, 8, st));
+    if (ix->ntotal > 0) {
+        const int grid = (int)((ix->ntotal + 255) / 256);
+        unsigned long long* out = (unsigned long long*)ix->xmax2_dev;
+        if (ix->plane > 0) mips::row_sumsq_max_kernel<mips::ElemF32><<<grid, 256, 0, st>>>(ix->rows_f32, ix->ntotal, ix->plane, out);
+        else if (ix->esize == 2) mips::row_sumsq_max_kernel<mips::ElemBF16><<<grid, 256, 0, st>>>((const uint16_t*)ix->rows, ix->ntotal, ix->ld, out);
+        else mips::row_sumsq_max_kernel<mips::ElemF8><<<grid, 256, 0, st>>>(ix->rows, ix->ntotal, ix->ld, out);
+        HIP_TRY(hipGetLastError());
+    }
+    ix->xmax2_valid = true;
     return MIPS_OK;
 }
 
@@ -600,6 +628,28 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     m.out_packed = d_out_packed;
     m.err = a.err;
     m.sticky = ix->sticky_dev;
+    m.ll = (want_v4 || want_v5 || want_f8x || short_lists) ? V4_KLL : KL;
+    m.bnd = nullptr;
+    m.flag = nullptr;
+    m.nflag = nullptr;
+    m.xmax2 = ix->xmax2_dev;
+    // MFMA score = fp32 accumulation of exact products (bf16 x bf16 and e4m3 x e4m3 fit fp32): |error| <= (terms) u
+    // sum |q_j x_j| <= d 2^-23 |q| |x| (u = 2^-23 allows truncating adders).  fp32-exact mode scans hi.qhi + hi.qlo +
+    // lo.qhi of bf16 splits: the dropped lo.qlo term adds 2^-16 |q| |x|, and there are three times the terms.
+    m.err_c = f32x ? (3.0 * (double)ix->d * 1.1920928955078125e-07 + 1.52587890625e-05) : (double)ix->d * 1.1920928955078125e-07;
+    if (ix->opt_margin != 0) {
+        rc = ix->mbnd.ensure((size_t)nq * sizeof(float));
+        if (rc) return rc;
+        rc = ix->mflag.ensure((size_t)nq);
+        if (rc) return rc;
+        rc = ensure_xmax2(ix, st);
+        if (rc) return rc;
+        m.xmax2 = ix->xmax2_dev;
+        m.bnd = (float*)ix->mbnd.p;
+        m.flag = (unsigned char*)ix->mflag.p;
+        m.nflag = (unsigned*)ix->gthr.p + (size_t)nq_pad * 8 + 1; // zeroed with the insert bounds by the query staging
+        ix->last_nflag_dev = m.nflag;
+    }
     // (1) K' best candidates per query by MFMA score, (2) lane-packed exact re-score + final order
     rc = ix->cand.ensure((size_t)nq * KL * sizeof(int));
     if (rc) return rc;
@@ -615,6 +665,96 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     else if (l2) mips::rescore_rank_kernel<KL, mips::ElemBF16, true><<<rgrid, 64, 0, st>>>(m, cand, nq);
     else mips::rescore_rank_kernel<KL, mips::ElemBF16, false><<<rgrid, 64, 0, st>>>(m, cand, nq);
     HIP_TRY(hipGetLastError());
+    return MIPS_OK;
+}
+
+// Margin check, host side.  The re-score flagged every query whose k-th exact score is within the MFMA error bound of
+// what the candidate pool may have excluded (aux_kernels.hpp).  When the call may synchronise (host buffers, or
+// "margin_check" = 2) the flagged queries are re-scanned with the widest lists (K' = 32; 16 on an fp8 index): their
+// staged rows are gathered into a compact query buffer, searched again, and the rows scattered over the first
+// results.  Queries still flagged after that are counted as unresolved (mips_index_margin_stats).
+template <int KL>
+int finish_margin(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, bool packed, int64_t idx_offset, bool out_dev,
+                  hipStream_t st) {
+    ix->last_flagged = -1;
+    ix->last_rescanned = 0;
+    ix->last_unresolved = 0;
+    if (ix->opt_margin == 0 || ix->rescan_depth != 0) return MIPS_OK;
+    if (out_dev && ix->opt_margin != 2) return MIPS_OK; // counted on the device only: nothing here may synchronise
+    if (!ix->nflag_host) HIP_TRY(hipHostMalloc((void**)&ix->nflag_host, 64, hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(ix->nflag_host, ix->last_nflag_dev, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int64_t n = (int64_t)ix->nflag_host[0];
+    ix->last_flagged = n;
+    if (n == 0) return MIPS_OK;
+    constexpr int WIDE = 32;
+    const bool f8 = ix->esize == 1;
+    const int wide = f8 ? (KL < 16 ? 16 : 0) : (KL < WIDE ? WIDE : 0);
+    if (wide == 0) { // already on the widest lists this storage type has
+        ix->last_unresolved = n;
+        return MIPS_OK;
+    }
+    // flagged query numbers
+    std::string flags((size_t)nq, '\0');
+    HIP_TRY(hipMemcpyAsync(&flags[0], ix->mflag.p, (size_t)nq, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::string idbuf((size_t)n * sizeof(int), '\0');
+    int* ids_h = reinterpret_cast<int*>(&idbuf[0]);
+    int64_t w = 0;
+    for (int64_t q = 0; q < nq && w < n; ++q)
+        if (flags[(size_t)q]) ids_h[w++] = (int)q;
+    if (w != n) return fail(MIPS_E_HIP, "margin check: flag count %lld does not match the flag array (%lld)", (long long)n, (long long)w);
+    int rc = ix->ids.ensure((size_t)n * sizeof(int));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(ix->ids.p, ids_h, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+    const int* ids = (const int*)ix->ids.p;
+    const int64_t n_pad = round_up(n, kQueryAlign);
+    const size_t row_bytes = (size_t)ix->ld * ix->esize;
+    rc = ix->qbuf2.ensure((size_t)n_pad * row_bytes);
+    if (rc) return rc;
+    mips::gather_rows_kernel<<<grid_for(n_pad * (int64_t)(row_bytes / 16), 256), 256, 0, st>>>((const unsigned char*)ix->qbuf.p, ids, n, n_pad,
+                                                                                              (int)row_bytes, (unsigned char*)ix->qbuf2.p);
+    if (ix->plane > 0) {
+        const size_t rb32 = (size_t)ix->plane * sizeof(float);
+        rc = ix->qf32b.ensure((size_t)n_pad * rb32);
+        if (rc) return rc;
+        mips::gather_rows_kernel<<<grid_for(n_pad * (int64_t)(rb32 / 16), 256), 256, 0, st>>>((const unsigned char*)ix->qf32.p, ids, n, n_pad, (int)rb32,
+                                                                                            (unsigned char*)ix->qf32b.p);
+    }
+    HIP_TRY(hipGetLastError());
+    rc = ix->tmp_s.ensure((size_t)n * k * sizeof(float));
+    if (rc) return rc;
+    rc = ix->tmp_i.ensure((size_t)n * k * sizeof(int64_t) * 2);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ix->gthr.p, 0, (size_t)(n_pad * 8 + 4) * sizeof(unsigned), st)); // insert bounds, error word, flag counter
+    std::swap(ix->qbuf, ix->qbuf2);
+    std::swap(ix->qf32, ix->qf32b);
+    const bool armed = ix->timing_armed;
+    char name_keep[sizeof ix->last_kernel];
+    std::memcpy(name_keep, ix->last_kernel, sizeof name_keep);
+    ix->timing_armed = false; // the bench's event window times the first scan only
+    ix->rescan_depth = 1;
+    float* ts = (float*)ix->tmp_s.p;
+    int64_t* ti = (int64_t*)ix->tmp_i.p;
+    if (wide == 32) rc = launch_search<32>(ix, n, k, ts, ti, packed ? ti : nullptr, idx_offset, st);
+    else rc = launch_search<16>(ix, n, k, ts, ti, packed ? ti : nullptr, idx_offset, st);
+    ix->rescan_depth = 0;
+    ix->timing_armed = armed;
+    std::memcpy(ix->last_kernel, name_keep, sizeof name_keep);
+    std::swap(ix->qbuf, ix->qbuf2);
+    std::swap(ix->qf32, ix->qf32b);
+    if (rc) return rc;
+    if (packed) {
+        mips::scatter_i64_kernel<<<grid_for(n * 2 * k, 256), 256, 0, st>>>(ti, ids, n, 2 * k, d_i);
+    } else {
+        mips::scatter_i64_kernel<<<grid_for(n * k, 256), 256, 0, st>>>(ti, ids, n, k, d_i);
+        mips::scatter_f32_kernel<<<grid_for(n * k, 256), 256, 0, st>>>(ts, ids, n, k, d_s);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ix->nflag_host, ix->last_nflag_dev, 4, hipMemcpyDeviceToHost, st)); // still flagged on the widest lists
+    HIP_TRY(hipStreamSynchronize(st));
+    ix->last_rescanned = n;
+    ix->last_unresolved = (int64_t)ix->nflag_host[0];
     return MIPS_OK;
 }
 
@@ -693,6 +833,15 @@ int mips_index_destroy(mips_index_t* ix) {
     ix->gthr.release();
     ix->cand.release();
     ix->qf32.release();
+    ix->mbnd.release();
+    ix->mflag.release();
+    ix->qbuf2.release();
+    ix->qf32b.release();
+    ix->tmp_s.release();
+    ix->tmp_i.release();
+    ix->ids.release();
+    if (ix->xmax2_dev) (void)hipFree(ix->xmax2_dev);
+    if (ix->nflag_host) (void)hipHostFree(ix->nflag_host);
     if (ix->rows_f32) (void)hipFree(ix->rows_f32);
     for (int e = 0; e < mips_index::kEvRing; ++e) {
         if (ix->ev0[e]) (void)hipEventDestroy(ix->ev0[e]);
@@ -729,6 +878,7 @@ int mips_index_add(mips_index_t* ix, const void* rows, int64_t n, int src_dtype,
     if (rc) return rc;
     ix->ntotal += n;
     if (!ix->phi_override) ix->phi_valid = false;
+    ix->xmax2_valid = false;
     return MIPS_OK;
 }
 
@@ -737,6 +887,7 @@ int mips_index_reset(mips_index_t* ix) {
     ix->ntotal = 0;
     ix->phi_valid = false;
     ix->phi_override = false;
+    ix->xmax2_valid = false;
     return MIPS_OK;
 }
 
@@ -811,6 +962,7 @@ int mips_index_add_synthetic(mips_index_t* ix, int64_t n, int64_t row0, uint64_t
     HIP_TRY(hipGetLastError());
     ix->ntotal += n;
     if (!ix->phi_override) ix->phi_valid = false; // as mips_index_add: an override stays until the caller renews it
+    ix->xmax2_valid = false;
     return MIPS_OK;
 }
 
@@ -905,14 +1057,19 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
         // sub-lists of 6, so MFMA ranks 1 .. 6 = k + 1 for certain and 7 .. 8 unless 6 better documents share the
         // sub-list (rows congruent mod 16 within a split).  Queries whose k-th exact score is too close to what the
         // pool may have lost are detected by the re-score and re-scanned with the widest lists (margin check below).
-        if (k <= 5)
+        if (k <= 5) {
             rc = launch_search<8>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st);
-        else if (k <= 7) // k + 1 = 6 is what Mips.search fetches for top_k = 5 with ignore_indexes (mips.py:388-398)
+            if (!rc) rc = finish_margin<8>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
+        } else if (k <= 7) { // k + 1 = 6 is what Mips.search fetches for top_k = 5 with ignore_indexes (mips.py:388-398)
             rc = launch_search<10>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st);
-        else if (k <= 13)
+            if (!rc) rc = finish_margin<10>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
+        } else if (k <= 13) {
             rc = launch_search<16>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st);
-        else
+            if (!rc) rc = finish_margin<16>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
+        } else {
             rc = launch_search<32>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st);
+            if (!rc) rc = finish_margin<32>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
+        }
         if (rc) return rc;
     }
     if (!out_dev) {
@@ -1058,7 +1215,10 @@ int mips_index_set_param(mips_index_t* ix, const char* name, int64_t value) {
     if (n == "nsplit") ix->opt_nsplit = (int)value;
     else if (n == "qgroups") ix->opt_qgroups = (int)value;
     else if (n == "variant") ix->opt_variant = (int)value;
-    else if (n == "spin_limit") ix->opt_spin_limit = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 30));
+    else if (n == "margin_check") {
+        if (value < 0 || value > 2) return fail(MIPS_E_INVALID, "mips_index_set_param: margin_check must be 0, 1 or 2");
+        ix->opt_margin = (int)value;
+    } else if (n == "spin_limit") ix->opt_spin_limit = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 30));
     else if (n == "sub") {
 #ifdef MIPS_EXPERIMENTAL
         ix->opt_sub = (int)value;
@@ -1081,6 +1241,25 @@ int mips_index_check_error(mips_index_t* ix, int synchronize, void* hip_stream) 
 }
 
 const char* mips_index_last_kernel(const mips_index_t* ix) { return ix ? ix->last_kernel : ""; }
+
+int mips_index_margin_stats(mips_index_t* ix, int64_t* flagged, int64_t* rescanned, int64_t* unresolved, int synchronize,
+                            void* hip_stream) {
+    if (!ix) return fail(MIPS_E_INVALID, "mips_index_margin_stats: index is NULL");
+    if (ix->last_flagged < 0 && synchronize && ix->opt_margin != 0 && ix->last_nflag_dev != nullptr) {
+        // the last search only counted on the device: fetch the count now
+        DeviceGuard g(ix->device);
+        unsigned n = 0;
+        HIP_TRY(hipMemcpyAsync(&n, ix->last_nflag_dev, 4, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+        ix->last_flagged = (int64_t)n;
+        ix->last_rescanned = 0;
+        ix->last_unresolved = (int64_t)n;
+    }
+    if (flagged) *flagged = ix->last_flagged;
+    if (rescanned) *rescanned = ix->last_rescanned;
+    if (unresolved) *unresolved = ix->last_unresolved;
+    return MIPS_OK;
+}
 
 int mips_scan_timing(mips_index_t* ix, float* out_sum_ms, int* out_count, int reset) {
     if (!ix) return fail(MIPS_E_INVALID, "mips_scan_timing: index is NULL");

@@ -471,36 +471,40 @@ def test_searches_on_two_streams_do_not_share_scratch_in_flight():
         assert torch.equal(b[1], rb[1]) and torch.equal(b[0], rb[0])
 
 
-def _big_properties(n, d, nq, k, plant_stride):
+def _big_properties(n, d, nq, k, plant_stride, dtype="bf16"):
     """Size-independent checks for indexes too large for the oracle: sortedness (ties by index), planted
     duplicates retrieved as their own nearest neighbour, returned scores == canonical re-score of the
     returned (query, document) pairs from independently regenerated rows, and agreement with the oracle
-    restricted to a window of the index that contains every planted document."""
-    ix = ram.MipsIndex(d)
+    restricted to a window of the index that contains every planted document.  dtype "fp8_e4m3": index and
+    queries are e4m3-quantised, every check is made on the quantised values."""
+    f8 = dtype != "bf16"
+    quant = synth.round_to_e4m3 if f8 else (lambda a: a)
+    ix = ram.MipsIndex(d, dtype=dtype)
     ix.reserve(n)
     ix.add_synthetic(n, row0=0, seed=synth.SEED_DOCS, kind=synth.KIND_GAUSS)
     qd = ram.synth_fill(nq, d, 0, synth.SEED_QUERIES, synth.KIND_GAUSS, dtype="bf16")
     plant_q = np.arange(0, nq, 16)
     plant_doc = (plant_q.astype(np.int64) * plant_stride + 7) % n
     rows = np.stack([synth.generate(synth.SEED_DOCS, int(r), 1, d, synth.KIND_GAUSS)[0] for r in plant_doc])
-    qd[torch.from_numpy(plant_q).cuda()] = torch.from_numpy(rows).cuda().bfloat16()
+    qd[torch.from_numpy(plant_q).cuda()] = torch.from_numpy(quant(rows)).cuda().bfloat16()
     s, i = ix.search(qd, k)
     torch.cuda.synchronize()
+    ix.check()
     s, i = s.cpu().numpy(), i.cpu().numpy()
-    q = qd.float().cpu().numpy()
+    q = quant(qd.float().cpu().numpy())
     assert (i >= 0).all() and (i < n).all()
     ds, di = np.diff(s, axis=1), np.diff(i, axis=1)
     assert ((ds < 0) | ((ds == 0) & (di > 0))).all()
     assert np.array_equal(i[plant_q, 0], plant_doc)
     uniq = np.unique(i)
-    regen = {int(r): synth.generate(synth.SEED_DOCS, int(r), 1, d, synth.KIND_GAUSS)[0] for r in uniq}
+    regen = {int(r): quant(synth.generate(synth.SEED_DOCS, int(r), 1, d, synth.KIND_GAUSS))[0] for r in uniq}
     docs = np.stack([regen[int(r)] for r in i.reshape(-1)]).reshape(nq, k, d)
     canon = np.stack([orc.canonical_pairs(q[j:j + 1], docs[j], np.arange(k)[None, :])[0] for j in range(nq)])
     assert np.array_equal(canon.astype(np.float32), s)
     # no document outside the returned set beats the k-th result: check on a random sample of rows
     rng = np.random.default_rng(1)
     sample = rng.integers(0, n, 4096)
-    xs = np.concatenate([synth.generate(synth.SEED_DOCS, int(r), 1, d, synth.KIND_GAUSS) for r in sample])
+    xs = quant(np.concatenate([synth.generate(synth.SEED_DOCS, int(r), 1, d, synth.KIND_GAUSS) for r in sample]))
     sc = (q[:64].astype(np.float64) @ xs.astype(np.float64).T).astype(np.float32)
     kth = s[:64, k - 1][:, None]
     listed = (sample[None, :, None] == i[:64, None, :]).any(-1)
@@ -511,6 +515,11 @@ def _big_properties(n, d, nq, k, plant_stride):
 def test_cfg3_size_single_gpu_properties():
     """BASELINE config 3's index (2^24 x 768 bf16, 25.8 GB) on ONE GPU, Q = 4096, k = 5."""
     _big_properties(1 << 24, 768, 4096, 5, 4099)
+
+
+def test_cfg5_fp8_full_size_properties():
+    """BASELINE config 5's index (2^24 x 768 e4m3, 12.9 GB) on ONE GPU, Q = 4096, k = 5 (scan_kernel_f8x)."""
+    _big_properties(1 << 24, 768, 4096, 5, 4099, dtype="fp8_e4m3")
 
 
 def test_cfg4_near_capacity_properties():
@@ -1273,3 +1282,94 @@ def test_sharded_l2_save_load_and_incremental_add(tmp_path):
     assert p0.phi() == old                                            # still the override
     p0.clear_phi()
     assert p0.phi() > old and p0.phi() == pytest.approx(float((big.astype(np.float64) ** 2).sum(1).max()), rel=1e-12)
+
+
+# ------------------------------------------------------------------ margin check: thin margins are detected, not assumed away
+def _near_duplicate_case(n=40000, d=768, nq=300, ncopy=10):
+    """Adversarial for the 16x16 kernels' sub-lists AND for fp32 accumulation.  Every document carries +1 on the first
+    256 coordinates and -1 on the last 256; the "star" queries carry 16 there, so for them every MFMA chain climbs to
+    4096, adds the informative middle part (|score| <= 256) at a granularity of 2^-11, and comes back -- the fp64
+    canonical score keeps 2^-15.  `ncopy` near-duplicates of the star document differ by ONE bf16 ulp steps in a
+    coordinate the star query weighs 2^-7: exact scores rise by 2^-14 per copy (distinct float32 values), MFMA scores
+    are (nearly) tied.  The copies sit 16 rows apart inside one split: one sub-list of 6 for all of them, which keeps the
+    LOWEST indices on ties -- while the exact top 5 are the HIGHEST-index copies."""
+    rng = np.random.default_rng(77)
+    x = synth.generate(231, 0, n, d, synth.KIND_GAUSS)
+    x[:, :256] = 1.0
+    x[:, 512:] = -1.0
+    q = synth.generate(232, 0, nq, d, synth.KIND_GAUSS)
+    sign = np.where(rng.random(256) < 0.5, -1.0, 1.0).astype(np.float32)
+    star_x = np.ones(d, np.float32)
+    star_x[512:] = -1.0
+    star_x[256:512] = sign
+    star_q = np.full(d, 16.0, np.float32)
+    star_q[256:512] = sign
+    j = 300
+    star_q[j] = 2.0 ** -7
+    rows = 1003 + 16 * np.arange(ncopy)
+    for t, r in enumerate(rows):
+        x[r] = star_x
+        x[r, j] = 1.0 + t * 2.0 ** -7                       # t bf16 ulps above 1.0
+    stars = np.arange(0, nq, 7)
+    q[stars] = star_q
+    assert np.array_equal(synth.round_to_bf16(x), x) and np.array_equal(synth.round_to_bf16(q), q)
+    return x, q, rows, stars
+
+
+@pytest.mark.parametrize("nq", [300, 100])                  # > 256: scan_kernel_v4 (4 sub-lists of 6); <= 256: scan_kernel_v3
+def test_near_duplicates_crowding_one_sub_list_are_certified(nq):
+    x, q, rows, stars = _near_duplicate_case(nq=nq)
+    k = 5
+    ix = _index(x)
+    es, ei = orc.search_exact_bruteforce(q[stars], x, k)     # tie-safe full enumeration for the star queries
+    assert np.array_equal(ei, np.tile(rows[::-1][:k], (len(stars), 1)))          # the k HIGHEST-index copies, best first
+    assert len(np.unique(es[0])) == k                                            # distinct canonical float32 scores
+    free = np.setdiff1d(np.arange(nq), stars)
+    fs, fi = orc.search_exact(q[free], x, k)
+    # NumPy in / out: the search synchronises anyway, so flagged queries are re-scanned with the widest lists
+    s, i = ix.search(q, k)
+    st = ix.margin_stats()
+    assert np.array_equal(i[stars], ei) and np.array_equal(s[stars], es)
+    assert np.array_equal(i[free], fi) and np.array_equal(s[free], fs)
+    assert st["flagged"] >= len(stars) and st["rescanned"] == st["flagged"] and st["unresolved"] == 0, st
+    # device tensors: by default flagged queries are only COUNTED (nothing may synchronise) ...
+    qd = torch.from_numpy(q).cuda()
+    ds, di = ix.search(qd, k)
+    st1 = ix.margin_stats()
+    assert st1["flagged"] == st["flagged"] and st1["rescanned"] == 0 and st1["unresolved"] == st["flagged"]
+    # ... and certified on request
+    ix.set_param("margin_check", 2)
+    ds, di = ix.search(qd, k)
+    assert ix.margin_stats() == st
+    assert np.array_equal(di.cpu().numpy()[stars], ei) and np.array_equal(ds.cpu().numpy()[stars], es)
+    assert np.array_equal(di.cpu().numpy()[free], fi)
+    pk = ix.search_packed(qd, k, 500)                         # the packed payload is patched the same way
+    assert np.array_equal(pk[..., 1].cpu().numpy()[stars], ei + 500)
+    # off: no flags, no statistics
+    ix.set_param("margin_check", 0)
+    ix.search(q, k)
+    assert ix.margin_stats()["flagged"] in (-1, 0)
+
+
+def test_margin_check_on_ordinary_data_flags_few_and_changes_nothing():
+    """Gaussian data: the rigorous error bound (d 2^-23 |q| |x|, ~0.07 at score scale 130) flags a few per cent of the
+    queries; re-scanning them returns the same rows (the first pass was right), every mode returns the oracle's bits."""
+    n, d, nq, k = 100003, 768, 600, 5
+    x = synth.generate(241, 0, n, d, synth.KIND_GAUSS)
+    q = synth.generate(242, 0, nq, d, synth.KIND_GAUSS)
+    es, ei = orc.search_exact(q, x, k)
+    for dtype in ("bf16", "fp8_e4m3"):
+        xx, qq = (x, q) if dtype == "bf16" else (synth.round_to_e4m3(x), synth.round_to_e4m3(q))
+        es, ei = orc.search_exact(qq, xx, k)
+        ix = ram.MipsIndex(d, dtype=dtype)
+        ix.add(x)
+        s, i = ix.search(q, k)                                 # certified (host buffers)
+        st = ix.margin_stats()
+        assert np.array_equal(i, ei) and np.array_equal(s, es)
+        assert 0 <= st["flagged"] <= nq // 4 and st["rescanned"] == st["flagged"] and st["unresolved"] <= st["flagged"], (dtype, st)
+        ds, di = ix.search(torch.from_numpy(q).cuda(), k)      # counted only
+        assert np.array_equal(di.cpu().numpy(), ei) and ix.margin_stats()["flagged"] == st["flagged"]
+    l2 = _index(x, metric=ram.METRIC_L2)
+    s, i = l2.search(q, 10)                                    # K' = 16 first pass, L2 distances, rescan with K' = 32
+    es, ei = orc.search_exact(q, x, 10, metric=orc.METRIC_L2)
+    assert np.array_equal(i, ei) and np.array_equal(s, es) and l2.margin_stats()["unresolved"] <= l2.margin_stats()["flagged"]
