@@ -329,6 +329,8 @@ def main():
             raise SystemExit("ranks disagree on the merged top-k")
     scan_ms_sum, scan_launches = index.local.scan_timing()
     scan_ms = scan_ms_sum / max(1, scan_launches)
+    # margin check of the last timed search on this rank's shard (counted on the device, read now: the run is over)
+    margin = index.local.margin_stats(synchronize=True)
 
     ms_per_step = elapsed / args.steps * 1e3
     value = nq * args.steps / elapsed
@@ -426,6 +428,9 @@ def main():
                        "rows_per_gpu": rows_per_gpu if world > 1 else local_rows},
             "distributed": dist_info,
             "step_ms": step_stats,
+            "margin_check": {"flagged_queries_last_step": margin["flagged"], "of": nq, "mode": "count only (device outputs; "
+                             "host-output and margin_check=2 searches re-scan flagged queries with K'=32 lists)",
+                             "bound": "exact k-th score within d*2^-23*|q|*max|x| of the best MFMA score outside the candidate pool"},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_torch": cpu_t, "parity_vs_cpu_sample": parity,
             "regimes": regimes,
             "index_build_s": t_build,

@@ -154,6 +154,20 @@ int mips_search(mips_index_t* index, const void* q, int q_dtype, int64_t nq, int
                 float* out_scores, int64_t* out_idx, int64_t idx_offset, int flags,
                 void* hip_stream);
 
+/* The device-resident scoring hook in one call: what retriever_generator.py:143-153 -> mips.py:421-422 does per
+ * training / generation step -- `_prepare_query` (row normalisation for the normalised inner-product index,
+ * mips.py:369-370), `search` with k or k + 1 hits and the `ignore_indexes` filter of mips.py:388-398 -- on DEVICE
+ * buffers, stream-ordered, no host hop:
+ *   q_device [nq, d] float32 or bf16; normalize != 0 (float32 only): faiss.normalize_L2 arithmetic, the caller's
+ *   buffer is NOT modified; ignore_device [nq] int64 or NULL; out_scores / out_idx DEVICE [nq, k].
+ * For the reference's own call shape (nq <= 16, bf16 index of <= 65536 rows, k + 1 <= 6) all of it is ONE kernel launch
+ * (csrc/tiny_search.hpp: staging, MFMA scan, select, exact re-score, filter); other shapes run the same steps as
+ * separate launches.  Results are identical either way ("tiny" = 0 in mips_index_set_param forces the general path;
+ * mips_search takes the one-launch kernel for eligible shapes as well). */
+int mips_search_fused(mips_index_t* index, const void* q_device, int q_dtype, int64_t nq, int k, int normalize,
+                      const int64_t* ignore_device, float* out_scores_device, int64_t* out_idx_device,
+                      int64_t idx_offset, void* hip_stream);
+
 /* Merge `parts` per-shard top-k lists into the global top-k (the step after the RCCL
  * all-gather; nothing in the reference corresponds, its index is replicated per rank,
  * lightning_model.py:180).  cand_s / cand_i: DEVICE [nq, parts*k] (shard-major inside a

@@ -365,6 +365,8 @@ struct MergeArgs {
     unsigned* sticky;    // host-visible (pinned, mapped) word of the index: set to 1 when `err` was set
     // ---- margin check: is the candidate pool provably wide enough?
     int ll;               // entries per running list of the scan kernel (6 for the 16x16 kernels, K' otherwise)
+    const float* pre_bnd; // optional [nq][npre]: bounds on what an EARLIER selection level excluded (tiny_search.hpp)
+    int npre;
     float* bnd;           // [nq] out of merge_select: no document OUTSIDE the pool has an MFMA score above this
     unsigned char* flag;  // [nq] out of the re-score: 1 = the k-th exact score is within the MFMA error of bnd
     unsigned* nflag;      // device counter of flagged queries of this call (nullptr: margin check off)
@@ -392,9 +394,8 @@ __device__ __forceinline__ float poison_score() { return __uint_as_float(0x7fc00
 //  4. rank the KL candidates of a query inside their lane group by (canonical score desc, idx asc)
 //     [L2: distance asc] and write the top k (or the packed all-gather payload).
 template <int KL>
-__global__ __launch_bounds__(64) void merge_select_kernel(MergeArgs p, int* cand) {
-    const int q = blockIdx.x;
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void merge_select_body(const MergeArgs& p, int* cand, int q, int lane, float* cand_s = nullptr,
+                                                  float* bnd_out = nullptr) {
     const float* ps = p.part_s + (size_t)q * p.ncand;
     const int* pi = p.part_i + (size_t)q * p.ncand;
 
@@ -407,11 +408,25 @@ __global__ __launch_bounds__(64) void merge_select_kernel(MergeArgs p, int* cand
     }
     // lb: the best score a document DROPPED from a full running list can have had = that list's last entry
     float lb = -INFINITY;
-    for (int c = lane; c < p.ncand; c += 64) {
-        const float s = ps[c];
-        const int id = pi[c];
-        if (ranks_before(s, id, ls[KL - 1], li[KL - 1])) list_insert_full<KL>(ls, li, s, id);
-        if (id != IDX_NONE && (c % p.ll) == p.ll - 1) lb = fmaxf(lb, s);
+    // 8 candidates per lane are loaded before any of them is looked at: the insert test is data dependent, and left
+    // alone the loop pays one memory round trip per candidate (lists freshly written by other workgroups: ~0.7 us each)
+    for (int c0 = lane; c0 < p.ncand; c0 += 8 * 64) {
+        float sv[8];
+        int iv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + 64 * u;
+            sv[u] = c < p.ncand ? ps[c] : -INFINITY;
+            iv[u] = c < p.ncand ? pi[c] : IDX_NONE;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + 64 * u;
+            const float s = sv[u];
+            const int id = iv[u];
+            if (ranks_before(s, id, ls[KL - 1], li[KL - 1])) list_insert_full<KL>(ls, li, s, id);
+            if (id != IDX_NONE && (c % p.ll) == p.ll - 1) lb = fmaxf(lb, s);
+        }
     }
     int ci = IDX_NONE;
     float last_pop = -INFINITY;
@@ -439,14 +454,23 @@ __global__ __launch_bounds__(64) void merge_select_kernel(MergeArgs p, int* cand
             ls[KL - 1] = -INFINITY;
             li[KL - 1] = IDX_NONE;
         }
-        if (lane == r) ci = bi;
+        if (lane == r) {
+            ci = bi;
+            if (cand_s) cand_s[(size_t)q * KL + r] = bs;
+        }
         if (bi != IDX_NONE) {
             last_pop = bs;
             ++pops;
         }
     }
     if (lane < KL) cand[(size_t)q * KL + lane] = ci;
-    if (p.bnd != nullptr) {
+    if (p.pre_bnd != nullptr)
+        for (int c = lane; c < p.npre; c += 64) lb = fmaxf(lb, p.pre_bnd[(size_t)q * p.npre + c]);
+    if (bnd_out != nullptr) { // an intermediate selection level: hand its bound to the next one
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lb = fmaxf(lb, __shfl_xor(lb, off));
+        if (lane == 0) *bnd_out = fmaxf(pops == KL ? last_pop : -INFINITY, lb);
+    } else if (p.bnd != nullptr) {
         // Every document outside the pool has an MFMA score <= bnd: list entries that were not popped rank behind
         // the pool's last member; documents rejected by a shared insert bound g scored below g <= the K'-th best
         // list entry (g is vouched for by K' list entries); documents dropped from a full list scored <= its last
@@ -457,15 +481,19 @@ __global__ __launch_bounds__(64) void merge_select_kernel(MergeArgs p, int* cand
     }
 }
 
+template <int KL>
+__global__ __launch_bounds__(64) void merge_select_kernel(MergeArgs p, int* cand) {
+    merge_select_body<KL>(p, cand, (int)blockIdx.x, (int)threadIdx.x);
+}
+
 template <int KL, typename EL, bool L2>
-__global__ __launch_bounds__(64) void rescore_rank_kernel(MergeArgs p, const int* cand, int64_t nq) {
+__device__ __forceinline__ void rescore_rank_body(const MergeArgs& p, const int* cand, int64_t nq, int64_t wave_index, int lane) {
     constexpr int QPW = 64 / KL; // queries per wave
-    const int lane = threadIdx.x;
-    const int64_t q = (int64_t)blockIdx.x * QPW + lane / KL;
+    const int64_t q = wave_index * QPW + lane / KL;
     const int slot = lane % KL;
     const bool inq = q < nq && lane < QPW * KL; // K' = 10: lanes 60..63 belong to no query
     if (p.err != nullptr && *p.err != 0u) { // the scan gave up on its barrier: nothing below can be trusted
-        if (blockIdx.x == 0 && lane == 0) __hip_atomic_store(p.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (wave_index == 0 && lane == 0) __hip_atomic_store(p.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (inq && slot < p.k) {
             const size_t o = (size_t)q * p.k + slot;
             if (p.out_packed) {
@@ -587,6 +615,11 @@ __global__ __launch_bounds__(64) void rescore_rank_kernel(MergeArgs p, const int
             p.out_i[o] = -1;
         }
     }
+}
+
+template <int KL, typename EL, bool L2>
+__global__ __launch_bounds__(64) void rescore_rank_kernel(MergeArgs p, const int* cand, int64_t nq) {
+    rescore_rank_body<KL, EL, L2>(p, cand, nq, (int64_t)blockIdx.x, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------ cross-shard merge (after the all-gather)

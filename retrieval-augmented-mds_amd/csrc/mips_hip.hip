@@ -18,6 +18,7 @@
 #include "scan_kernel_f8x.hpp"
 #include "scan_kernel_v4.hpp"
 #include "scan_kernel_v5.hpp"
+#include "tiny_search.hpp"
 
 namespace {
 
@@ -132,6 +133,8 @@ struct mips_index {
     int64_t last_flagged = -1, last_rescanned = 0, last_unresolved = 0;
     int rescan_depth = 0;
     unsigned* last_nflag_dev = nullptr;
+    int opt_tiny = 1;              // 1 = searches of <= 16 queries over a small bf16 index take the one-launch kernel
+    unsigned* tiny_words = nullptr; // [0] ticket (reset by the kernel's last workgroup), [1] flag counter
     int opt_variant = 0; // 0 = automatic, 1 = scan_kernel (128x128 tiles), 3 = scan_kernel_v3 (32x32x16), 4 = scan_kernel_v4 (16x16x32)
     hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
     int ev_count = 0; // pairs recorded since the last reset (saturates at kEvRing)
@@ -629,6 +632,8 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     m.err = a.err;
     m.sticky = ix->sticky_dev;
     m.ll = (want_v4 || want_v5 || want_f8x || short_lists) ? V4_KLL : KL;
+    m.pre_bnd = nullptr;
+    m.npre = 0;
     m.bnd = nullptr;
     m.flag = nullptr;
     m.nflag = nullptr;
@@ -665,6 +670,93 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     else if (l2) mips::rescore_rank_kernel<KL, mips::ElemBF16, true><<<rgrid, 64, 0, st>>>(m, cand, nq);
     else mips::rescore_rank_kernel<KL, mips::ElemBF16, false><<<rgrid, 64, 0, st>>>(m, cand, nq);
     HIP_TRY(hipGetLastError());
+    return MIPS_OK;
+}
+
+// One-launch search for the reference's own call shape (tiny_search.hpp): <= 16 queries, bf16 index of at most
+// kTinyMaxRows rows, k_fetch <= 6.  q must be device memory.
+constexpr int64_t kTinyMaxRows = 1 << 16;
+bool tiny_eligible(const mips_index* ix, int64_t nq, int k_fetch) {
+    return ix->opt_tiny != 0 && nq >= 1 && nq <= 16 && k_fetch <= mips::TINY_MAXK && ix->ntotal > 0 && ix->ntotal <= kTinyMaxRows &&
+           ix->esize == 2 && ix->plane == 0 && ix->ld <= 1024 && ix->ld % 128 == 0 && ix->rescan_depth == 0;
+}
+
+int tiny_search(mips_index* ix, const void* q_dev, int q_dtype, int64_t nq, int k_fetch, int k_out, int normalize, const int64_t* ignore_dev,
+                float* d_s, int64_t* d_i, bool packed, int64_t idx_offset, hipStream_t st) {
+    if (!ix->tiny_words) {
+        HIP_TRY(hipMalloc((void**)&ix->tiny_words, 64));
+        HIP_TRY(hipMemsetAsync(ix->tiny_words, 0, 64, st)); // the ticket starts at 0; the kernel's last workgroup resets it
+    }
+    const int ntiles = (int)((ix->ntotal + 15) / 16);
+    const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>(128, (ntiles + 7) / 8));
+    mips::TinyArgs a;
+    a.docs = (const uint16_t*)ix->rows;
+    a.q = q_dev;
+    a.q_is_f32 = q_dtype == MIPS_DTYPE_F32 ? 1 : 0;
+    a.normalize = normalize;
+    a.nq = (int)nq;
+    a.d = (int)ix->d;
+    a.ld = ix->ld;
+    a.ntotal = ix->ntotal;
+    a.ntiles = ntiles;
+    a.nwaves = nwg * 4;
+    a.ticket = ix->tiny_words;
+    a.ignore = ignore_dev;
+    a.k_out = k_out;
+    a.out_s = d_s;
+    a.out_i = d_i;
+    a.out_packed = packed ? d_i : nullptr;
+    const size_t ncand = (size_t)nwg * mips::TINY_POOL; // per query: the 8 best of every workgroup
+    int rc = ix->part_s.ensure(16 * (ncand + nwg) * sizeof(float)); // + the workgroups' bounds behind the candidates
+    if (rc) return rc;
+    rc = ix->part_i.ensure(16 * ncand * sizeof(int));
+    if (rc) return rc;
+    mips::MergeArgs& m = a.m;
+    m.part_s = (const float*)ix->part_s.p;
+    m.part_i = (const int*)ix->part_i.p;
+    m.ncand = (int)ncand;
+    m.pre_bnd = (const float*)ix->part_s.p + 16 * ncand;
+    m.npre = nwg;
+    m.docs = ix->rows;
+    m.qbuf = nullptr;
+    m.ld = ix->ld;
+    m.k = k_fetch;
+    m.metric = ix->call_metric;
+    m.phi = ix->phi;
+    m.idx_offset = idx_offset;
+    m.out_s = nullptr;
+    m.out_i = nullptr;
+    m.out_packed = nullptr;
+    m.err = nullptr;
+    m.sticky = ix->sticky_dev;
+    m.ll = 0x7fffffff; // final level: no "last entry of a full list" rule, the workgroups' bounds carry that
+    m.bnd = nullptr;
+    m.flag = nullptr;
+    m.nflag = nullptr;
+    m.xmax2 = ix->xmax2_dev;
+    m.err_c = (double)ix->d * 1.1920928955078125e-07;
+    ix->last_flagged = -1;
+    ix->last_rescanned = 0;
+    ix->last_unresolved = 0;
+    ix->last_nflag_dev = nullptr;
+    if (ix->opt_margin != 0) {
+        rc = ix->mbnd.ensure(16 * sizeof(float));
+        if (rc) return rc;
+        rc = ix->mflag.ensure(16);
+        if (rc) return rc;
+        rc = ensure_xmax2(ix, st);
+        if (rc) return rc;
+        m.xmax2 = ix->xmax2_dev;
+        m.bnd = (float*)ix->mbnd.p;
+        m.flag = (unsigned char*)ix->mflag.p;
+        m.nflag = ix->tiny_words + 1;
+        ix->last_nflag_dev = m.nflag;
+    }
+    const int lds = 16 * ix->ld * 2 + 2 * 16 * 96 * 4 + 3 * 512 + 16 * 8 * 8;
+    if (ix->call_metric == MIPS_METRIC_L2) mips::tiny_search_kernel<true><<<nwg, 256, lds, st>>>(a);
+    else mips::tiny_search_kernel<false><<<nwg, 256, lds, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    set_kernel_name(ix, "mips::tiny_search_kernel<%s>", ix->call_metric == MIPS_METRIC_L2 ? "true" : "false");
     return MIPS_OK;
 }
 
@@ -842,6 +934,7 @@ int mips_index_destroy(mips_index_t* ix) {
     ix->ids.release();
     if (ix->xmax2_dev) (void)hipFree(ix->xmax2_dev);
     if (ix->nflag_host) (void)hipHostFree(ix->nflag_host);
+    if (ix->tiny_words) (void)hipFree(ix->tiny_words);
     if (ix->rows_f32) (void)hipFree(ix->rows_f32);
     for (int e = 0; e < mips_index::kEvRing; ++e) {
         if (ix->ev0[e]) (void)hipEventDestroy(ix->ev0[e]);
@@ -1016,11 +1109,39 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
         d_i = (int64_t*)ix->out_i.p;
     }
 
+    bool done = false;
     if (ix->ntotal == 0) {
         const int64_t total = nq * k;
         mips::fill_empty_kernel<<<(int)((total + 255) / 256), 256, 0, st>>>(d_s, d_i, packed ? d_i : nullptr, total, ix->call_metric);
         HIP_TRY(hipGetLastError());
-    } else {
+        done = true;
+    } else if (tiny_eligible(ix, nq, k)) {
+        // the reference's own call shape (<= 16 queries, small knowledge base): one launch (tiny_search.hpp)
+        if (ix->call_metric == MIPS_METRIC_L2) {
+            int rc = compute_phi(ix, st);
+            if (rc) return rc;
+        }
+        const void* qd = q;
+        if (!(flags & MIPS_Q_DEVICE)) {
+            const size_t qbytes = (size_t)nq * ix->d * (q_dtype == MIPS_DTYPE_F32 ? 4 : 2);
+            int rc = ix->stage.ensure(qbytes);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(ix->stage.p, q, qbytes, hipMemcpyHostToDevice, st));
+            qd = ix->stage.p;
+        }
+        int rc = tiny_search(ix, qd, q_dtype, nq, k, k, 0, nullptr, d_s, d_i, packed, idx_offset, st);
+        if (rc) return rc;
+        done = true;
+        if (ix->opt_margin != 0 && (!out_dev || ix->opt_margin == 2)) {
+            // certify: a flagged query sends the whole (tiny) call through the general path and its re-scan
+            if (!ix->nflag_host) HIP_TRY(hipHostMalloc((void**)&ix->nflag_host, 64, hipHostMallocDefault));
+            HIP_TRY(hipMemcpyAsync(ix->nflag_host, ix->last_nflag_dev, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            ix->last_flagged = (int64_t)ix->nflag_host[0];
+            done = ix->last_flagged == 0;
+        }
+    }
+    if (!done) {
         if (ix->call_metric == MIPS_METRIC_L2) {
             int rc = compute_phi(ix, st);
             if (rc) return rc;
@@ -1081,6 +1202,62 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
         if (bad) return bad;
     }
     return MIPS_OK;
+}
+
+int mips_search_fused(mips_index_t* ix, const void* q_device, int q_dtype, int64_t nq, int k, int normalize, const int64_t* ignore_device,
+                      float* out_scores_device, int64_t* out_idx_device, int64_t idx_offset, void* hip_stream) {
+    if (!ix) return fail(MIPS_E_INVALID, "mips_search_fused: index is NULL");
+    if (nq < 0 || k < 0) return fail(MIPS_E_INVALID, "mips_search_fused: negative nq or k");
+    const int k_fetch = k + (ignore_device ? 1 : 0);
+    if (k_fetch > MIPS_MAX_K) return fail(MIPS_E_UNSUPPORTED, "mips_search_fused: k = %d exceeds MIPS_MAX_K = %d", k_fetch, MIPS_MAX_K);
+    if (!src_dtype_ok(ix, q_dtype)) return fail(MIPS_E_INVALID, "mips_search_fused: q_dtype must be F32 or BF16");
+    if (normalize && q_dtype != MIPS_DTYPE_F32) return fail(MIPS_E_INVALID, "mips_search_fused: normalize needs float32 queries");
+    if (nq == 0 || k == 0) return MIPS_OK;
+    if (!q_device || !out_idx_device || !out_scores_device) return fail(MIPS_E_INVALID, "mips_search_fused: NULL buffer");
+    DeviceGuard g(ix->device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (tiny_eligible(ix, nq, k_fetch)) {
+        const int prev = take_scan_error(ix, "mips_search_fused");
+        if (prev) return prev;
+        ORDER_ON(ix, st);
+        ix->call_metric = ix->metric;
+        if (ix->call_metric == MIPS_METRIC_L2) {
+            int rc = compute_phi(ix, st);
+            if (rc) return rc;
+        }
+        int rc = tiny_search(ix, q_device, q_dtype, nq, k_fetch, k, normalize, ignore_device, out_scores_device, out_idx_device, false,
+                             idx_offset, st);
+        if (rc) return rc;
+        if (ix->opt_margin != 2) return MIPS_OK;
+        if (!ix->nflag_host) HIP_TRY(hipHostMalloc((void**)&ix->nflag_host, 64, hipHostMallocDefault));
+        HIP_TRY(hipMemcpyAsync(ix->nflag_host, ix->last_nflag_dev, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        ix->last_flagged = (int64_t)ix->nflag_host[0];
+        if (ix->last_flagged == 0) return MIPS_OK;
+        // a flagged query: the unfused path below certifies it
+    }
+    // general form: the same steps as separate launches
+    const void* qsrc = q_device;
+    if (normalize) {
+        const size_t qbytes = (size_t)nq * ix->d * sizeof(float);
+        int rc = ix->qf32b.ensure(qbytes); // (free on every index but the fp32-exact one during a re-scan, which this is not)
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->qf32b.p, q_device, qbytes, hipMemcpyDeviceToDevice, st));
+        rc = mips_l2_normalize((float*)ix->qf32b.p, nq, ix->d, ix->device, hip_stream);
+        if (rc) return rc;
+        qsrc = ix->qf32b.p;
+    }
+    if (!ignore_device)
+        return mips_search(ix, qsrc, q_dtype, nq, k, out_scores_device, out_idx_device, idx_offset, MIPS_Q_DEVICE | MIPS_OUT_DEVICE, hip_stream);
+    int rc = ix->out_s.ensure((size_t)nq * k_fetch * sizeof(float));
+    if (rc) return rc;
+    rc = ix->out_i.ensure((size_t)nq * k_fetch * sizeof(int64_t));
+    if (rc) return rc;
+    rc = mips_search(ix, qsrc, q_dtype, nq, k_fetch, (float*)ix->out_s.p, (int64_t*)ix->out_i.p, idx_offset, MIPS_Q_DEVICE | MIPS_OUT_DEVICE,
+                     hip_stream);
+    if (rc) return rc;
+    return mips_filter_ignore((const float*)ix->out_s.p, (const int64_t*)ix->out_i.p, ignore_device, nq, k_fetch, k, out_scores_device,
+                              out_idx_device, ix->device, hip_stream);
 }
 
 int mips_merge_topk(const float* cand_s, const int64_t* cand_i, int64_t nq, int parts, int k, int metric, float* out_s,
@@ -1215,6 +1392,7 @@ int mips_index_set_param(mips_index_t* ix, const char* name, int64_t value) {
     if (n == "nsplit") ix->opt_nsplit = (int)value;
     else if (n == "qgroups") ix->opt_qgroups = (int)value;
     else if (n == "variant") ix->opt_variant = (int)value;
+    else if (n == "tiny") ix->opt_tiny = value != 0 ? 1 : 0;
     else if (n == "margin_check") {
         if (value < 0 || value > 2) return fail(MIPS_E_INVALID, "mips_index_set_param: margin_check must be 0, 1 or 2");
         ix->opt_margin = (int)value;

@@ -193,6 +193,32 @@ class MipsIndex:
         del keep
         return D, I
 
+    def search_fused(self, x, k: int, normalize: bool = False, ignore=None, idx_offset: int = 0):
+        """The scoring hook's search in one call on CUDA tensors (include/mips_hip.h, mips_search_fused): optional
+        row normalisation of float32 queries (the caller's tensor is not modified), top-k, and the ignore filter of
+        sotasum/mips.py:388-398 (`ignore`: int64 ids, one per query).  One kernel launch for <= 16 queries on a small
+        index; nothing synchronises."""
+        import torch
+
+        k = int(k)
+        ptr, code, is_dev, nq, keep = self._as_buffer(x, "search")
+        if not is_dev:
+            raise ValueError("search_fused needs a CUDA tensor")
+        dev = f"cuda:{self.device}"
+        ig = None
+        if ignore is not None:
+            ig = torch.as_tensor(ignore, device=dev, dtype=torch.int64).contiguous()
+            if ig.shape != (nq,):
+                raise ValueError(f"ignore_indexes: expected {nq} ids, got {tuple(ig.shape)}")
+        D = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        with self._mutex:
+            _lib.check(self._lib.mips_search_fused(self._h, ptr, code, nq, k, int(bool(normalize)),
+                                                   ig.data_ptr() if ig is not None else None, D.data_ptr(), I.data_ptr(),
+                                                   int(idx_offset), _stream_handle(self.device)), "mips_search_fused")
+        del keep, ig
+        return D, I
+
     def search_packed(self, x, k: int, idx_offset: int = 0):
         """Device-only search returning the all-gather payload: CUDA int64 [nq, k, 2] =
         {float32 score bits, index + idx_offset} (sharded.py)."""

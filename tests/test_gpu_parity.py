@@ -1373,3 +1373,95 @@ def test_margin_check_on_ordinary_data_flags_few_and_changes_nothing():
     s, i = l2.search(q, 10)                                    # K' = 16 first pass, L2 distances, rescan with K' = 32
     es, ei = orc.search_exact(q, x, 10, metric=orc.METRIC_L2)
     assert np.array_equal(i, ei) and np.array_equal(s, es) and l2.margin_stats()["unresolved"] <= l2.margin_stats()["flagged"]
+
+
+# ------------------------------------------------------------------ the reference's own call shape in one launch
+@pytest.mark.parametrize("n,nq,d,k,metric", [(10000, 8, 768, 5, 0), (33, 16, 768, 5, 0), (65536, 3, 1024, 6, 0), (4099, 16, 100, 1, 0),
+                                               (10000, 8, 768, 5, 1), (3, 2, 64, 5, 0), (20011, 11, 512, 4, 1)])
+def test_tiny_search_is_the_general_path_in_one_launch(n, nq, d, k, metric):
+    """<= 16 queries on a small bf16 index take tiny_search_kernel (staging + MFMA scan + select + exact re-score in
+    ONE launch): bit-identical to the general path ("tiny" = 0) and to the oracle, NumPy and CUDA call shapes, packed
+    payload and row offsets included; the ticket of its last-workgroup hand-off survives repeated calls."""
+    x = synth.generate(251, 0, n, d, synth.KIND_GAUSS)
+    q = synth.generate(252, 0, nq, d, synth.KIND_GAUSS)
+    es, ei = orc.search_exact(q, x, k, metric=metric, idx_offset=700)
+    ix = _index(x, metric=metric)
+    qd = torch.from_numpy(q).cuda()
+    for rep in range(3):
+        s, i = ix.search(q, k, 700)
+        assert ix.last_kernel.startswith("mips::tiny_search_kernel")
+        assert np.array_equal(i, ei) and np.array_equal(s, es), rep
+        ds, di = ix.search(qd, k, 700)
+        assert np.array_equal(di.cpu().numpy(), ei) and np.array_equal(ds.cpu().numpy(), es)
+        ds, di = ix.search(qd.bfloat16(), k, 700)
+        assert np.array_equal(di.cpu().numpy(), ei) and np.array_equal(ds.cpu().numpy(), es)
+    pk = ix.search_packed(qd, k, 700)
+    assert np.array_equal(pk[..., 1].cpu().numpy(), ei)
+    assert np.array_equal(pk[..., 0].to(torch.int32).view(torch.float32).cpu().numpy(), es)
+    st = ix.margin_stats()
+    ix.set_param("tiny", 0)
+    gs, gi = ix.search(qd, k, 700)
+    assert not ix.last_kernel.startswith("mips::tiny") and torch.equal(gi, di) and torch.equal(gs, ds)
+    assert ix.margin_stats()["flagged"] == st["flagged"]          # the same queries are flagged by either path
+
+
+def test_tiny_search_ties_and_stream_of_calls():
+    x = synth.generate(5, 0, 3000, 768, synth.KIND_LATTICE)
+    q = synth.generate(6, 0, 16, 768, synth.KIND_LATTICE)
+    x[10] = x[700]
+    x[333] = x[700]
+    q[0] = x[700]
+    ix = _index(x)
+    es, ei = orc.search_exact_bruteforce(q, x, 5)
+    qd = torch.from_numpy(q).cuda()
+    outs = [ix.search(qd, 5) for _ in range(20)]                   # back to back, no synchronisation in between
+    torch.cuda.synchronize()
+    for s, i in outs:
+        assert np.array_equal(i.cpu().numpy(), ei) and np.array_equal(s.cpu().numpy(), es)
+    assert ix.last_kernel.startswith("mips::tiny_search_kernel") and list(ei[0][:3]) == [10, 333, 700]
+    g = torch.cuda.CUDAGraph()                                     # one kernel node: capturable
+    buf = qd.clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ix.search(buf, 5)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        s, i = ix.search(buf, 5)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(i.cpu().numpy(), ei)
+
+
+@pytest.mark.parametrize("metric,normalize", [(0, True), (0, False), (1, True)])
+def test_fused_hook_search_prepare_search_ignore_in_one_call(tmp_path, metric, normalize):
+    """Mips.search_device -> mips_search_fused: `_prepare_query` + `search` + the ignore filter of mips.py:388-398 as
+    one library call (one launch at B = 8, N = 10^4): equal to the separate device steps and to the oracle."""
+    n, d, k, b = 10000, 768, 5, 8
+    rng = np.random.default_rng(3)
+    emb = (synth.generate(261, 0, n, d, synth.KIND_GAUSS) * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
+    qs = (synth.generate(262, 0, b, d, synth.KIND_GAUSS) * rng.uniform(0.5, 2.0, (b, 1))).astype(np.float32)
+    m = ram.Mips(ram.MipsArgs(mips_metric_type=metric, mips_normalize=normalize, mips_tmp_folder=str(tmp_path)))
+    m.build_index(emb)
+    index = m.embeddings.get_index(m.index_name).faiss_index
+    stored = synth.bf16_bits_to_f32(index.rows_bf16())
+    qd = torch.from_numpy(qs).cuda()
+    keep = qd.clone()
+    # separate device steps (the round-1 form)
+    qn = ram.l2_normalize_(qd.clone()) if (normalize and metric == 0) else qd
+    rs, ri = index.search(qn, k + 1)
+    ignore = ri[:, 1].clone()                                      # ban the second hit of every query
+    fs, fi = ram.filter_ignore(rs, ri, ignore, k)
+    s, i = m.search_device(qd, ignore_indexes=ignore, k=k)
+    assert index.last_kernel.startswith("mips::tiny_search_kernel")
+    assert torch.equal(i, fi) and torch.equal(s, fs) and torch.equal(qd, keep)
+    s0, i0 = m.search_device(qd, k=k)
+    assert torch.equal(i0, ri[:, :k]) and torch.equal(s0, rs[:, :k])
+    # the oracle on what the device searched with
+    q_used = synth.round_to_bf16(qn.cpu().numpy())
+    es, ei = orc.mips_search(lambda qq, kk: orc.search_exact(q_used, stored, kk, metric=metric), q_used, ignore.cpu().tolist(), k)
+    assert [list(map(int, r)) for r in ei] == i.cpu().tolist()
+    # larger batches take the same call through separate launches: same answers
+    big = torch.cat([qd] * 5)[:33]
+    s2, i2 = m.search_device(big, ignore_indexes=torch.cat([ignore] * 5)[:33], k=k)
+    assert not index.last_kernel.startswith("mips::tiny") and torch.equal(i2[:b], i) and torch.equal(s2[:b], s)

@@ -27,7 +27,26 @@ for rows, nq, iters, name in ((1 << 20, 4096, 20, "BASELINE config 2"), (10000, 
     def dev_call():
         ix.search(q_dev, 5); torch.cuda.synchronize()
     med_d, min_d = timed(dev_call, iters)
-    out.append({"workload": f"{name}: {rows}x768 bf16 index, Q={nq}, k=5",
-                "host_numpy_f32_in_out_ms": {"median": med_h * 1e3, "min": min_h * 1e3}, "host_queries_per_s": nq / med_h,
-                "device_resident_ms": {"median": med_d * 1e3, "min": min_d * 1e3}, "device_queries_per_s": nq / med_d})
+    rec = {"workload": f"{name}: {rows}x768 bf16 index, Q={nq}, k=5", "kernel": ix.last_kernel,
+           "host_numpy_f32_in_out_ms": {"median": med_h * 1e3, "min": min_h * 1e3}, "host_queries_per_s": nq / med_h,
+           "device_resident_ms": {"median": med_d * 1e3, "min": min_d * 1e3}, "device_queries_per_s": nq / med_d}
+    if nq <= 16:
+        # the same call through the general path (separate launches), and the GPU time alone from HIP events
+        def gpu_ms(fn, n=200):
+            fn(); torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n): fn()
+            b.record(); torch.cuda.synchronize()
+            return a.elapsed_time(b) / n
+        rec["one_launch_gpu_ms_per_call_back_to_back"] = gpu_ms(lambda: ix.search(q_dev, 5))
+        ig = torch.arange(nq, device="cuda")
+        rec["fused_hook_normalize_ignore_gpu_ms"] = gpu_ms(lambda: ix.search_fused(q_dev.float(), 5, normalize=True, ignore=ig))
+        ix.set_param("tiny", 0)
+        med_g, min_g = timed(dev_call, iters)
+        rec["general_path_device_resident_ms"] = {"median": med_g * 1e3, "min": min_g * 1e3}
+        rec["general_path_gpu_ms_per_call_back_to_back"] = gpu_ms(lambda: ix.search(q_dev, 5))
+        rec["general_path_kernel"] = ix.last_kernel
+        ix.set_param("tiny", 1)
+    out.append(rec)
 print(json.dumps(out, indent=1))
