@@ -432,6 +432,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     a.tiles_per_split = tps;
     a.nsplit = nsplit;
     a.nqt = nqt;
+    a.nq = (int)nq;
     a.qgroups = qgroups;
     a.qt_per_group = qt_per_group;
     a.splits_per_group = nsplit / (8 / qgroups);

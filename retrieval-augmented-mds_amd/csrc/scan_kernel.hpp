@@ -51,6 +51,7 @@ struct ScanArgs {
     int tiles_per_split;
     int nsplit;           // multiple of 8
     int nqt;              // query tiles
+    int nq;               // real queries (rows nq .. of the last tile are zero padding)
     int qgroups;          // QG in {1,2,4,8}: query-tile groups; XCD x serves group x % QG, split group x / QG
     int qt_per_group;     // ceil(nqt / QG)
     int splits_per_group; // nsplit / (8 / QG)

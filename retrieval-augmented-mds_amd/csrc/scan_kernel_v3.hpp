@@ -105,6 +105,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
     if (b1 > p.ntiles) b1 = p.ntiles;
     const int nb = b1 > b0 ? b1 - b0 : 0;
 
+    // A wave whose queries are ALL padding (small searches: 8 real queries leave 7 of the 8 waves of the one query tile
+    // without work) still brings its share of every document block and takes part in the block barrier, but skips
+    // the MFMA chain and the epilogue: fewer issue slots and less power spent next to the document stream, which is all
+    // that matters in this HBM-bound regime.
+    const bool idle_wave = (qt * V3_TN + wave * NQB * 32) >= p.nq;
+
     // ---- stationary query fragments: lane holds Q[q0 + l31][16 s + 8 h .. +8) for every k16-step s
     bf16x8 bq[NQB][KS16];
 #pragma unroll
@@ -260,9 +266,27 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
     // during an issue, which right after the barrier it could not, both waves being there together)
     // `refresh`: does this block re-read the shared threshold words (and apply them in its epilogue)?
     auto block = [&](bool refresh, int blk, int stage, const unsigned char* pbase, int pstage) {
-        const unsigned char* sa = smem + stage * STAGE_BYTES + rd_row;
+        if (idle_wave) { // (uniform) the same VMEM operation sequence as a working wave: refresh, then the pieces
+            if (TMODE) refresh_thresholds(false);
+            if (DMA_SPREAD) issue(pbase, pstage);
+            if (SPLIT_BAR) arrive();
+            return;
+        }
+        // Fragment address = stage + slab (s >> 2) * 4096 + row * 128 + ((2 (s & 3) + h) ^ swz) * 16.  2 j + h = 2 j ^ h
+        // (h is bit 0), so the lane part is a0 ^ (j << 5) with ONE per-lane value a0 = row * 128 + (h ^ swz) * 16 -- the
+        // four variants are derived where they are used (an opaque v_xor: hipcc would otherwise keep all four in
+        // registers for the whole block, which together with the 192 fragment registers cost the 8-wave configuration a
+        // spilled B fragment, reloaded at the top of every block behind a vmcnt(0) that drained the LDS-DMA ring).
+        const unsigned char* sa = smem + stage * STAGE_BYTES;
+        const unsigned a0 = (unsigned)(rd_row + ((h ^ rd_swz) << 4));
         auto lds_frag = [&](int s) {
-            return *reinterpret_cast<const bf16x8*>(sa + (s >> 2) * 4096 + (((2 * (s & 3) + h) ^ rd_swz) << 4));
+            unsigned av = a0;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (WAVES == 8 && (s & 3) != 0) asm volatile("v_xor_b32 %0, %2, %1" : "=v"(av) : "v"(a0), "n"((s & 3) << 5)); // (a literal must be src0 of the VOP2 form)
+            else
+#endif
+                av = a0 ^ (unsigned)((s & 3) << 5);
+            return *reinterpret_cast<const bf16x8*>(sa + (s >> 2) * 4096 + av);
         };
         f32x16 acc[NQB];
 #pragma unroll
