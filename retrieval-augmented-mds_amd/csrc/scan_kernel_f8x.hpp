@@ -62,6 +62,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_f8x(ScanArgsF8 pa) {
     const int split = (xcd / p.qgroups) * p.splits_per_group + j / p.qt_per_group;
     if (qt >= p.nqt) return;
     if (p.spin_limit < 0 && tid == 0) *p.err = 1u; // test-only: force the scan-error path (include/mips_hip.h, "spin_limit")
+    const bool idle_wave = (qt * TN + wave * 32) >= p.nq;
 
     const int b0 = split * p.tiles_per_split; // "tiles" are 64-document blocks here
     int b1 = b0 + p.tiles_per_split;
@@ -160,6 +161,12 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_f8x(ScanArgsF8 pa) {
     };
 
     auto block = [&](bool refresh, int blk, int stage, const unsigned char* pbase, int pstage) {
+        if (idle_wave) { // all of this wave's queries are padding (scan_kernel_v3.hpp): bring the documents, skip the arithmetic
+            refresh_thresholds(false);
+            issue(pbase, pstage);
+            arrive();
+            return;
+        }
         const unsigned char* sa = smem + stage * STAGE_BYTES;
         // flattened step t = tl * KS + s: tile tl = rows 16 tl .. 16 tl + 15 (2048 B further down a slab), slab s
         auto lds_frag = [&](int t) {

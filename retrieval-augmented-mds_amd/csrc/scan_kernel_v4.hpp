@@ -65,6 +65,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
     const int split = (xcd / p.qgroups) * p.splits_per_group + j / p.qt_per_group;
     if (qt >= p.nqt) return;
     if (p.spin_limit < 0 && tid == 0) *p.err = 1u; // test-only: force the scan-error path (include/mips_hip.h, "spin_limit")
+    const bool idle_wave = (qt * TN + wave * 32) >= p.nq;
 
     const int b0 = split * p.tiles_per_split;
     int b1 = b0 + p.tiles_per_split;
@@ -203,6 +204,12 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
     };
 
     auto block = [&](bool refresh, int blk, int stage, const unsigned char* pbase, int pstage) {
+        if (idle_wave) { // all of this wave's queries are padding (scan_kernel_v3.hpp): bring the documents, skip the arithmetic
+            refresh_thresholds(false);
+            issue(pbase, pstage);
+            arrive();
+            return;
+        }
         const unsigned char* sa = smem + stage * STAGE_BYTES;
         const int rd0 = rd0_of(lane_id_here());
         // flattened step t = half * KS32 + s
