@@ -18,6 +18,7 @@
 #include "scan_kernel_f8x.hpp"
 #include "scan_kernel_v4.hpp"
 #include "scan_kernel_v5.hpp"
+#include "scan_kernel_ks.hpp"
 #include "tiny_search.hpp"
 
 namespace {
@@ -373,7 +374,12 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     const int64_t nq_pad = round_up(nq, kQueryAlign);
     const int nqt = (int)((nq + tn - 1) / tn);
     const bool want_v4 = !want_v5 && (v4_forced || (v4_auto && nqt > 1));
-    const int lists = (want_v4 || want_v5 || want_f8x) ? 4 : 2;                  // running lists per (query, split)
+    // scan_kernel_ks (K split over a wave pair, two waves per SIMD): row pitch 1024, k <= 5.  Selectable ("variant" =
+    // 6), not the default: measured 30.6 vs 31.3 ms at 2^22 x 1024 against the one-wave-per-SIMD scan_kernel_v3
+    // configuration (profiles/r2_pitch1024) -- both sit on the L2 -> LDS fill of 128 stationary queries per CU
+    const bool ks_shape = ix->ld == 1024 && KL == 8 && ix->esize == 2 && ix->plane == 0;
+    const bool want_ks = ks_shape && ix->opt_variant == 6;
+    const int lists = want_ks ? 8 : (want_v4 || want_v5 || want_f8x) ? 4 : 2;                  // running lists per (query, split)
     const int ntiles = (int)((ix->ntotal + tm - 1) / tm);
     // Index splits (a multiple of 8: one XCD group each).  The grid nqt x nsplit should come in whole
     // "rounds" of wg_target resident workgroups: among the multiples of 8 up to 64 take the one whose last
@@ -415,7 +421,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
 #else
     const bool short_lists = false;
 #endif
-    const size_t ncand = (size_t)nsplit * lists * ((want_v4 || want_v5 || want_f8x || short_lists) ? V4_KLL : KL);
+    const size_t ncand = (size_t)nsplit * lists * ((want_v4 || want_v5 || want_ks || want_f8x || short_lists) ? V4_KLL : KL);
     int rc = ix->part_s.ensure((size_t)nq_pad * ncand * sizeof(float));
     if (rc) return rc;
     rc = ix->part_i.ensure((size_t)nq_pad * ncand * sizeof(int));
@@ -453,7 +459,15 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
 
     const int grid = qt_per_group * qgroups * nsplit;
     const int slot = ix->ev_next;
-    if (want_v5) {
+    if (want_ks) {
+        if constexpr (KL == 8) {
+            const int lds = 2 * mips::V3_DB * ix->ld * 2 + 8 * 1024 + 8 * 2048 + 64; // ring + class-word copies + exchange slots + counters
+            HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel_ks<V4_KLL, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            if (ix->timing_armed) HIP_TRY(hipEventRecord(ix->ev0[slot], st));
+            mips::scan_kernel_ks<V4_KLL, 32, 2><<<grid, 512, lds, st>>>(a);
+            set_kernel_name(ix, "mips::scan_kernel_ks<%d, 32, 2, 0>", V4_KLL);
+        }
+    } else if (want_v5) {
         if constexpr (KL == 8) {
             const int lds = 3 * mips::V3_DB * ix->ld * 2 + 4 * 2048 + 1024 + 16; // ring + threshold words + dump area + arrival counter
             auto go5 = [&](auto kern) -> int {
@@ -632,7 +646,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     m.out_packed = d_out_packed;
     m.err = a.err;
     m.sticky = ix->sticky_dev;
-    m.ll = (want_v4 || want_v5 || want_f8x || short_lists) ? V4_KLL : KL;
+    m.ll = (want_v4 || want_v5 || want_ks || want_f8x || short_lists) ? V4_KLL : KL;
     m.pre_bnd = nullptr;
     m.npre = 0;
     m.bnd = nullptr;

@@ -1465,3 +1465,31 @@ def test_fused_hook_search_prepare_search_ignore_in_one_call(tmp_path, metric, n
     big = torch.cat([qd] * 5)[:33]
     s2, i2 = m.search_device(big, ignore_indexes=torch.cat([ignore] * 5)[:33], k=k)
     assert not index.last_kernel.startswith("mips::tiny") and torch.equal(i2[:b], i) and torch.equal(s2[:b], s)
+
+
+def test_pitch_1024_k_split_kernel_is_bit_identical():
+    """scan_kernel_ks ("variant" = 6): a wave pair splits K at row pitch 1024, partial sums meet in LDS.  Same bits as
+    the default (scan_kernel_v3's one-wave-per-SIMD configuration) and as the oracle, ragged sizes, single- and
+    multi-tile query counts, ties."""
+    for n, nq, d, k in ((70001, 300, 1024, 5), (150001, 700, 1000, 5), (64 * 37 + 5, 129, 800, 4), (5000, 40, 1024, 1)):
+        ix = ram.MipsIndex(d)
+        ix.add_synthetic(n, row0=0, seed=171, kind=synth.KIND_GAUSS)
+        q = ram.synth_fill(nq, d, 0, 172, synth.KIND_GAUSS)
+        ref_s, ref_i = ix.search(q, k)
+        assert "scan_kernel_v3" in ix.last_kernel
+        ix.set_param("variant", 6)
+        for ns in (0, 8, 40):
+            ix.set_param("nsplit", ns)
+            s, i = ix.search(q, k)
+            assert "scan_kernel_ks" in ix.last_kernel and torch.equal(i, ref_i) and torch.equal(s, ref_s), (n, nq, d, ns)
+        ix.check()
+    x = synth.generate(5, 0, 3000, 1024, synth.KIND_LATTICE)
+    ql = synth.generate(6, 0, 300, 1024, synth.KIND_LATTICE)
+    x[10] = x[700]
+    x[333] = x[700]
+    ql[0] = x[700]
+    ix = _index(x)
+    ix.set_param("variant", 6)
+    s, i = ix.search(ql, 5)
+    es, ei = orc.search_exact_bruteforce(ql, x, 5)
+    assert np.array_equal(i, ei) and np.array_equal(s, es) and "scan_kernel_ks" in ix.last_kernel
