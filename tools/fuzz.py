@@ -26,6 +26,8 @@ while time.time() < t_end:
     lattice = bool(rng.random() < 0.3)
     n = int(rng.integers(1, 3000 if lattice else 50000))
     nq = int(rng.integers(1, 40 if lattice else 700))
+    if rng.random() < 0.25:
+        nq = int(rng.integers(1, 17))                                  # the one-launch kernel's shape
     if a.big and not lattice:
         n, nq = int(rng.integers(50000, 300000)), int(rng.integers(257, 1500))
         d = int(rng.choice([384, 512, 640, 700, 768, 768, 768, 1024]))
@@ -53,19 +55,30 @@ while time.time() < t_end:
     knobs = {}
     if rng.random() < 0.4:
         knobs["nsplit"] = int(rng.choice([8, 16, 24, 40, 64, 128]))
+    if rng.random() < 0.4:
+        knobs["variant"] = int(rng.choice([1, 3, 4, 5, 6]))   # 5 / 6 apply at their row pitches only (ignored elsewhere)
+    if rng.random() < 0.15:
+        knobs["tiny"] = 0
     if rng.random() < 0.3:
-        knobs["variant"] = int(rng.choice([1, 3, 4]))
+        knobs["margin_check"] = int(rng.choice([0, 2]))
     if rng.random() < 0.2:
         knobs["qgroups"] = int(rng.choice([1, 2, 4, 8]))
     for name, v in knobs.items():
         ix.set_param(name, v)
-    s, i = ix.search(q, k)
+    dev = bool(rng.random() < 0.4)                                     # CUDA tensors in / out instead of NumPy
+    if dev:
+        import torch
+        s, i = ix.search(torch.from_numpy(q).cuda(), k)
+        ix.check()
+        s, i = s.cpu().numpy(), i.cpu().numpy()
+    else:
+        s, i = ix.search(q, k)
     if lattice:
         es, ei = orc.search_exact_bruteforce(qs, xs, k, metric=metric)
     else:
         es, ei = orc.search_exact(qs, xs, k, metric=metric)
     ok = np.array_equal(i, ei) and np.array_equal(s, es)
-    print(f"case {case}: dtype={dtype} n={n} nq={nq} d={d} k={k} metric={metric} lattice={lattice} knobs={knobs} -> {'ok' if ok else 'MISMATCH'}", flush=True)
+    print(f"case {case}: dtype={dtype} n={n} nq={nq} d={d} k={k} metric={metric} lattice={lattice} knobs={knobs} dev={dev} kernel={ix.last_kernel} -> {'ok' if ok else 'MISMATCH'}", flush=True)
     if not ok:
         bad = np.where((i != ei).any(axis=1) | (s != es).any(axis=1))[0]
         print("rows differing:", bad[:10], "\n gpu", i[bad[0]], s[bad[0]], "\n ora", ei[bad[0]], es[bad[0]])
