@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--index-dtype", default="bf16", choices=["bf16", "fp8_e4m3"],
                     help="fp8_e4m3 = BASELINE config 5 (index and queries quantised to OCP e4m3, fp8 MFMA)")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: run every step's all-gather + merge before the next scan")
+    ap.add_argument("--pipeline-single", action="store_true", help="N = 1: split-tail pipelining of consecutive steps (ShardedMipsIndex.search_async)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N > 1 path on ONE GPU (all ranks on cuda:0, host-staged collective)")
     ap.add_argument("--launch-check", action="store_true",
@@ -271,7 +272,10 @@ def main():
     # N > 1 over RCCL: consecutive steps are independent query batches, so the exchange step of batch t (the ONE
     # all-gather + merge, on a side stream) overlaps the shard scan of batch t + 1 (ShardedMipsIndex.search_async).
     # Every one of the K steps still completes inside the timed region.
-    pipelined = world > 1 and args.backend == "nccl" and not args.no_pipeline
+    # (At N = 1 the same call would put the ~45 us tail of step t beside the scan of step t + 1; measured: no gain --
+    # 4.794 vs 4.786 ms per step -- because a scan workgroup owns all 512 registers of every SIMD of its CU, so the
+    # tail's waves only get on the machine when a scan workgroup leaves.  --pipeline-single turns it on anyway.)
+    pipelined = ((world > 1 and args.backend == "nccl") or (world == 1 and args.pipeline_single)) and not args.no_pipeline
 
     def run_steps(count):
         out = None
@@ -424,7 +428,7 @@ def main():
                                    f"resident in HBM, top-k={k}, exact; BASELINE config 2 at the defaults "
                                    f"(config 5 with --index-dtype fp8_e4m3)",
                        "index_rows": n, "dim": d, "queries": nq, "k": k,
-                       "parallelism": (f"row-sharded x{world} + 1 all-gather" + (", exchange of step t overlapped with the scan of step t+1" if pipelined else "")) if world > 1 else "single GPU",
+                       "parallelism": (f"row-sharded x{world} + 1 all-gather" + (", tail + exchange of step t overlapped with the scan of step t+1" if pipelined else "")) if world > 1 else ("single GPU" + (", tail (select + exact re-score) of step t overlapped with the scan of step t+1" if pipelined else "")),
                        "rows_per_gpu": rows_per_gpu if world > 1 else local_rows},
             "distributed": dist_info,
             "step_ms": step_stats,

@@ -154,6 +154,16 @@ int mips_search(mips_index_t* index, const void* q, int q_dtype, int64_t nq, int
                 float* out_scores, int64_t* out_idx, int64_t idx_offset, int flags,
                 void* hip_stream);
 
+/* mips_search with its two halves on two streams: query staging and the fused scan are enqueued on scan_stream, the
+ * candidate selection and exact re-score on tail_stream (behind an event), device outputs only.  Consecutive calls use
+ * two alternating scratch sets, so the scan of search t + 1 starts right behind the scan of search t while the tail
+ * of t -- and whatever the caller enqueues behind it on tail_stream: the all-gather and merge of a row-sharded search
+ * (sharded.py) -- runs beside it.  The results are complete on tail_stream; any other stream must wait for it (an
+ * event recorded on tail_stream after the call).  Margin check: counted only (mips_index_margin_stats).  Nothing in
+ * the reference corresponds. */
+int mips_search_split(mips_index_t* index, const void* q, int q_dtype, int64_t nq, int k, float* out_scores,
+                      int64_t* out_idx, int64_t idx_offset, int flags, void* scan_stream, void* tail_stream);
+
 /* The device-resident scoring hook in one call: what retriever_generator.py:143-153 -> mips.py:421-422 does per
  * training / generation step -- `_prepare_query` (row normalisation for the normalised inner-product index,
  * mips.py:369-370), `search` with k or k + 1 hits and the `ignore_indexes` filter of mips.py:388-398 -- on DEVICE

@@ -124,6 +124,7 @@ def _bind(lib):
         "mips_index_add_synthetic": (i32, [vp, i64, i64, u64, i32, vp]),
         "mips_synth_fill": (i32, [vp, i64, i64, i64, u64, i32, i32, i32, vp]),
         "mips_search": (i32, [vp, vp, i32, i64, i32, vp, vp, i64, i32, vp]),
+        "mips_search_split": (i32, [vp, vp, i32, i64, i32, vp, vp, i64, i32, vp, vp]),
         "mips_search_fused": (i32, [vp, vp, i32, i64, i32, i32, vp, vp, vp, i64, vp]),
         "mips_merge_topk": (i32, [vp, vp, i64, i32, i32, i32, vp, vp, i32, vp]),
         "mips_merge_topk_packed": (i32, [vp, i64, i32, i32, i32, vp, vp, i32, vp]),
@@ -152,7 +153,7 @@ EXPORTS = (
     "mips_index_dim", "mips_index_metric", "mips_index_phi", "mips_index_set_phi", "mips_index_read_rows",
     "mips_index_add_synthetic", "mips_synth_fill", "mips_search", "mips_merge_topk",
     "mips_merge_topk_packed", "mips_filter_ignore", "mips_cosine_rescore", "mips_cosine_rescore_bias", "mips_l2_normalize", "mips_rows_max_sumsq", "mips_index_set_param", "mips_scan_timing",
-    "mips_index_check_error", "mips_index_last_kernel", "mips_cosine_rescore_backward", "mips_index_margin_stats", "mips_search_fused",
+    "mips_index_check_error", "mips_index_last_kernel", "mips_cosine_rescore_backward", "mips_index_margin_stats", "mips_search_fused", "mips_search_split",
 )
 
 

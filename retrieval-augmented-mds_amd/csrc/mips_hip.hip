@@ -134,6 +134,13 @@ struct mips_index {
     int64_t last_flagged = -1, last_rescanned = 0, last_unresolved = 0;
     int rescan_depth = 0;
     unsigned* last_nflag_dev = nullptr;
+    // Split-tail searches (mips_search_split): the scan runs on one stream, select + exact re-score on another, so the
+    // NEXT search's scan can start behind this one's.  Two scratch sets alternate; `alt_*` is the one not in use.
+    Buffer alt_qbuf, alt_qf32, alt_gthr, alt_part_s, alt_part_i, alt_cand, alt_mbnd, alt_mflag;
+    int cur_set = 0;
+    hipEvent_t scan_done = nullptr;
+    hipEvent_t tail_done[2] = {nullptr, nullptr};
+    bool tail_pending[2] = {false, false};
     int opt_tiny = 1;              // 1 = searches of <= 16 queries over a small bf16 index take the one-launch kernel
     unsigned* tiny_words = nullptr; // [0] ticket (reset by the kernel's last workgroup), [1] flag counter
     int opt_variant = 0; // 0 = automatic, 1 = scan_kernel (128x128 tiles), 3 = scan_kernel_v3 (32x32x16), 4 = scan_kernel_v4 (16x16x32)
@@ -331,9 +338,22 @@ int ensure_xmax2(mips_index* ix, hipStream_t st) {
     return MIPS_OK;
 }
 
+void swap_scratch_sets(mips_index* ix) {
+    std::swap(ix->qbuf, ix->alt_qbuf);
+    std::swap(ix->qf32, ix->alt_qf32);
+    std::swap(ix->gthr, ix->alt_gthr);
+    std::swap(ix->part_s, ix->alt_part_s);
+    std::swap(ix->part_i, ix->alt_part_i);
+    std::swap(ix->cand, ix->alt_cand);
+    std::swap(ix->mbnd, ix->alt_mbnd);
+    std::swap(ix->mflag, ix->alt_mflag);
+    ix->cur_set ^= 1;
+}
+
+// tail_st: stream of the select + exact re-score launches (nullptr or == st: the scan's own stream)
 template <int KL>
 int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_out_i, int64_t* d_out_packed,
-                  int64_t idx_offset, hipStream_t st) {
+                  int64_t idx_offset, hipStream_t st, hipStream_t tail_st = nullptr, bool split = false) {
     // variant 3 (query-stationary, LDS-DMA): the whole K of a wave's 32 queries lives in its VGPRs, so it
     // exists for a few row lengths only: 256 / 512 / 768 (8 waves, 2 per SIMD) and 1024 (4 waves, 1 per SIMD)
     int variant = ix->opt_variant;
@@ -674,6 +694,12 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     rc = ix->cand.ensure((size_t)nq * KL * sizeof(int));
     if (rc) return rc;
     int* cand = (int*)ix->cand.p;
+    const hipStream_t scan_st = st;
+    if (split) { // the tail goes to its own stream, behind the scan
+        HIP_TRY(hipEventRecord(ix->scan_done, scan_st));
+        HIP_TRY(hipStreamWaitEvent(tail_st, ix->scan_done, 0));
+        st = tail_st;
+    }
     mips::merge_select_kernel<KL><<<(int)nq, 64, 0, st>>>(m, cand);
     HIP_TRY(hipGetLastError());
     const bool l2 = ix->call_metric == MIPS_METRIC_L2;
@@ -685,6 +711,10 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     else if (l2) mips::rescore_rank_kernel<KL, mips::ElemBF16, true><<<rgrid, 64, 0, st>>>(m, cand, nq);
     else mips::rescore_rank_kernel<KL, mips::ElemBF16, false><<<rgrid, 64, 0, st>>>(m, cand, nq);
     HIP_TRY(hipGetLastError());
+    if (split) {
+        HIP_TRY(hipEventRecord(ix->tail_done[ix->cur_set], st));
+        ix->tail_pending[ix->cur_set] = true;
+    }
     return MIPS_OK;
 }
 
@@ -914,6 +944,12 @@ int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, 
         mips_index_destroy(ix);
         return fail(MIPS_E_HIP, "hipEventCreate failed");
     }
+    if (hipEventCreateWithFlags(&ix->scan_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ix->tail_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ix->tail_done[1], hipEventDisableTiming) != hipSuccess) {
+        mips_index_destroy(ix);
+        return fail(MIPS_E_HIP, "hipEventCreate failed");
+    }
     // the sticky scan-error word: pinned host memory the device writes to (coherent, mapped)
     if (hipHostMalloc((void**)&ix->sticky_host, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void**)&ix->sticky_dev, ix->sticky_host, 0) != hipSuccess) {
@@ -956,6 +992,17 @@ int mips_index_destroy(mips_index_t* ix) {
         if (ix->ev1[e]) (void)hipEventDestroy(ix->ev1[e]);
     }
     if (ix->busy) (void)hipEventDestroy(ix->busy);
+    if (ix->scan_done) (void)hipEventDestroy(ix->scan_done);
+    for (int e = 0; e < 2; ++e)
+        if (ix->tail_done[e]) (void)hipEventDestroy(ix->tail_done[e]);
+    ix->alt_qbuf.release();
+    ix->alt_qf32.release();
+    ix->alt_gthr.release();
+    ix->alt_part_s.release();
+    ix->alt_part_i.release();
+    ix->alt_cand.release();
+    ix->alt_mbnd.release();
+    ix->alt_mflag.release();
     if (ix->sticky_host) (void)hipHostFree(ix->sticky_host);
     delete ix;
     return MIPS_OK;
@@ -1091,8 +1138,22 @@ int mips_synth_fill(void* out_device, int64_t n, int64_t d, int64_t row0, uint64
     return MIPS_OK;
 }
 
+static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k, float* out_scores, int64_t* out_idx,
+                       int64_t idx_offset, int flags, void* hip_stream, void* tail_stream);
+
 int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k, float* out_scores, int64_t* out_idx,
                 int64_t idx_offset, int flags, void* hip_stream) {
+    return search_impl(ix, q, q_dtype, nq, k, out_scores, out_idx, idx_offset, flags, hip_stream, hip_stream);
+}
+
+int mips_search_split(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k, float* out_scores, int64_t* out_idx,
+                      int64_t idx_offset, int flags, void* scan_stream, void* tail_stream) {
+    if (!(flags & MIPS_OUT_DEVICE)) return fail(MIPS_E_INVALID, "mips_search_split: device outputs only (MIPS_OUT_DEVICE)");
+    return search_impl(ix, q, q_dtype, nq, k, out_scores, out_idx, idx_offset, flags, scan_stream, tail_stream);
+}
+
+static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k, float* out_scores, int64_t* out_idx,
+                       int64_t idx_offset, int flags, void* hip_stream, void* tail_stream) {
     if (!ix) return fail(MIPS_E_INVALID, "mips_search: index is NULL");
     if (nq < 0 || k < 0) return fail(MIPS_E_INVALID, "mips_search: negative nq or k");
     if (k > MIPS_MAX_K) return fail(MIPS_E_UNSUPPORTED, "mips_search: k = %d exceeds MIPS_MAX_K = %d", k, MIPS_MAX_K);
@@ -1112,6 +1173,15 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
     const bool packed = (flags & MIPS_OUT_PACKED) != 0;
     ix->call_metric = (flags & MIPS_FORCE_IP) ? MIPS_METRIC_IP : ix->metric;
     if (packed && !out_dev) return fail(MIPS_E_INVALID, "mips_search: MIPS_OUT_PACKED requires MIPS_OUT_DEVICE");
+    // split-tail form: the other scratch set, so that this scan may run while the previous search's tail still reads
+    // its lists; whichever set is about to be used, a tail still pending on it comes first
+    hipStream_t tail_st = (hipStream_t)tail_stream;
+    const bool split = tail_st != st;
+    if (split) swap_scratch_sets(ix);
+    if (ix->tail_pending[ix->cur_set]) {
+        HIP_TRY(hipStreamWaitEvent(st, ix->tail_done[ix->cur_set], 0));
+        ix->tail_pending[ix->cur_set] = false;
+    }
 
     float* d_s = out_scores;
     int64_t* d_i = out_idx;
@@ -1147,7 +1217,7 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
         int rc = tiny_search(ix, qd, q_dtype, nq, k, k, 0, nullptr, d_s, d_i, packed, idx_offset, st);
         if (rc) return rc;
         done = true;
-        if (ix->opt_margin != 0 && (!out_dev || ix->opt_margin == 2)) {
+        if (ix->opt_margin != 0 && !split && (!out_dev || ix->opt_margin == 2)) {
             // certify: a flagged query sends the whole (tiny) call through the general path and its re-scan
             if (!ix->nflag_host) HIP_TRY(hipHostMalloc((void**)&ix->nflag_host, 64, hipHostMallocDefault));
             HIP_TRY(hipMemcpyAsync(ix->nflag_host, ix->last_nflag_dev, 4, hipMemcpyDeviceToHost, st));
@@ -1194,17 +1264,21 @@ int mips_search(mips_index_t* ix, const void* q, int q_dtype, int64_t nq, int k,
         // sub-list (rows congruent mod 16 within a split).  Queries whose k-th exact score is too close to what the
         // pool may have lost are detected by the re-score and re-scanned with the widest lists (margin check below).
         if (k <= 5) {
-            rc = launch_search<8>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st);
-            if (!rc) rc = finish_margin<8>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
+            rc = launch_search<8>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st, tail_st, split);
+            if (!rc && !split) rc = finish_margin<8>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
+            if (!rc && split) ix->last_flagged = -1; // counted on the device only
         } else if (k <= 7) { // k + 1 = 6 is what Mips.search fetches for top_k = 5 with ignore_indexes (mips.py:388-398)
-            rc = launch_search<10>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st);
-            if (!rc) rc = finish_margin<10>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
+            rc = launch_search<10>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st, tail_st, split);
+            if (!rc && !split) rc = finish_margin<10>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
+            if (!rc && split) ix->last_flagged = -1; // counted on the device only
         } else if (k <= 13) {
-            rc = launch_search<16>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st);
-            if (!rc) rc = finish_margin<16>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
+            rc = launch_search<16>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st, tail_st, split);
+            if (!rc && !split) rc = finish_margin<16>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
+            if (!rc && split) ix->last_flagged = -1; // counted on the device only
         } else {
-            rc = launch_search<32>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st);
-            if (!rc) rc = finish_margin<32>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
+            rc = launch_search<32>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st, tail_st, split);
+            if (!rc && !split) rc = finish_margin<32>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
+            if (!rc && split) ix->last_flagged = -1; // counted on the device only
         }
         if (rc) return rc;
     }

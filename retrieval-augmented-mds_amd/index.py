@@ -161,10 +161,12 @@ class MipsIndex:
         return out
 
     # ------------------------------------------------------------------ search
-    def search(self, x, k: int, idx_offset: int = 0, force_ip: bool = False):
+    def search(self, x, k: int, idx_offset: int = 0, force_ip: bool = False, tail_stream=None):
         """faiss Index.search(x, k) -> (D, I)  (sotasum/mips.py:383-386).
         NumPy in -> NumPy out; torch CUDA tensor in -> torch CUDA tensors out (stream-ordered, no
-        synchronisation)."""
+        synchronisation).  tail_stream (a torch.cuda.Stream, CUDA tensors only): candidate selection and exact
+        re-score run there instead of on the current stream (mips_search_split) -- the results are complete on
+        THAT stream."""
         import torch
 
         k = int(k)
@@ -188,8 +190,14 @@ class MipsIndex:
         if force_ip:
             flags |= _lib.FORCE_IP  # inner-product ranking on an L2 index (Mips.np_search)
         with self._mutex:
-            _lib.check(self._lib.mips_search(self._h, ptr, code, nq, k, ds, di, int(idx_offset), flags, stream),
-                       "mips_search")
+            if tail_stream is not None and is_dev:
+                D.record_stream(tail_stream)
+                I.record_stream(tail_stream)
+                _lib.check(self._lib.mips_search_split(self._h, ptr, code, nq, k, ds, di, int(idx_offset), flags, stream,
+                                                       int(tail_stream.cuda_stream)), "mips_search_split")
+            else:
+                _lib.check(self._lib.mips_search(self._h, ptr, code, nq, k, ds, di, int(idx_offset), flags, stream),
+                           "mips_search")
         del keep
         return D, I
 
@@ -219,9 +227,9 @@ class MipsIndex:
         del keep, ig
         return D, I
 
-    def search_packed(self, x, k: int, idx_offset: int = 0):
+    def search_packed(self, x, k: int, idx_offset: int = 0, tail_stream=None):
         """Device-only search returning the all-gather payload: CUDA int64 [nq, k, 2] =
-        {float32 score bits, index + idx_offset} (sharded.py)."""
+        {float32 score bits, index + idx_offset} (sharded.py).  tail_stream: as in search()."""
         import torch
 
         k = int(k)
@@ -231,10 +239,16 @@ class MipsIndex:
         if not is_dev:
             raise ValueError("search_packed needs a CUDA tensor")
         out = torch.empty((nq, k, 2), dtype=torch.int64, device=f"cuda:{self.device}")
+        flags = _lib.Q_DEVICE | _lib.OUT_DEVICE | _lib.OUT_PACKED
         with self._mutex:
-            _lib.check(self._lib.mips_search(self._h, ptr, code, nq, k, None, out.data_ptr(), int(idx_offset),
-                                             _lib.Q_DEVICE | _lib.OUT_DEVICE | _lib.OUT_PACKED,
-                                             _stream_handle(self.device)), "mips_search")
+            if tail_stream is not None:
+                out.record_stream(tail_stream)
+                _lib.check(self._lib.mips_search_split(self._h, ptr, code, nq, k, None, out.data_ptr(), int(idx_offset), flags,
+                                                       _stream_handle(self.device), int(tail_stream.cuda_stream)),
+                           "mips_search_split")
+            else:
+                _lib.check(self._lib.mips_search(self._h, ptr, code, nq, k, None, out.data_ptr(), int(idx_offset), flags,
+                                                 _stream_handle(self.device)), "mips_search")
         del keep
         return out
 

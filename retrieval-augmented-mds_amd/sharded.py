@@ -213,39 +213,46 @@ class ShardedMipsIndex:
             return self._out
 
     def search_async(self, q, k: int, _force_collective: bool = False):
-        """search() split in two: the local scan (+ select, exact re-score) is enqueued on the current stream,
-        the exchange step -- the ONE all-gather and the replicated merge -- on a side stream behind it, so the
-        caller can enqueue the NEXT batch's scan before asking for this batch's result().  Independent query
-        batches then overlap their exchange with the next scan (the collective is latency-bound: ~tens of us
-        against a ~0.6 ms shard scan at 8 GPUs).  Falls back to the synchronous path when there is nothing to
-        overlap (one rank, host queries, gloo)."""
+        """search() split over two streams so that consecutive, independent query batches overlap:
+          current stream   query staging + the fused scan of this shard (mips_search_split);
+          side stream      candidate selection + exact re-score, then the exchange step -- the ONE all-gather and the
+                           replicated merge (ranks > 1).
+        The caller can enqueue the NEXT batch's scan before asking for this batch's result(): the scan of batch t + 1
+        starts right behind the scan of batch t, the ~45 us tail and the latency-bound collective (tens of us against a
+        ~0.6 ms shard scan at 8 GPUs) run beside it.  Falls back to the synchronous path when there is nothing to
+        overlap with (host queries, injected device steps, gloo)."""
         import torch
         import torch.distributed as dist
 
         backend = dist.get_backend(self.group) if dist.is_initialized() else None
+        collective = self.world > 1 or _force_collective
         fast = (self.local is not None and self._fast and isinstance(q, torch.Tensor) and q.is_cuda
-                and backend == "nccl" and (self.world > 1 or _force_collective))
+                and (backend == "nccl" or not collective))
         if not fast:
             return ShardedMipsIndex._Pending(self.search(q, k), None, None)
         from .index import merge_topk_packed
 
-        packed = self.local.search_packed(q, k, self.lo)  # current stream
-        nq = packed.shape[0]
-        main = torch.cuda.current_stream(q.device)
-        ready = torch.cuda.Event()
-        ready.record(main)
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=q.device, priority=-1)  # its short kernels go first when CUs free up
         side = self._side
+        main = torch.cuda.current_stream(q.device)
+        if not collective:
+            out = self.local.search(q, k, self.lo, tail_stream=side)  # scan here, select + re-score on the side stream
+            done = torch.cuda.Event()
+            done.record(side)
+            return ShardedMipsIndex._Pending(out, done, (q,), self.local)
+        packed = self.local.search_packed(q, k, self.lo, tail_stream=side)
+        nq = packed.shape[0]
+        ready = torch.cuda.Event()
+        ready.record(main)  # (the one-launch kernel of tiny searches writes its results on the main stream)
         with torch.cuda.stream(side):
             side.wait_event(ready)
-            packed.record_stream(side)
             gathered = torch.empty((self.world * nq, k, 2), dtype=torch.int64, device=packed.device)
             dist.all_gather_into_tensor(gathered, packed, group=self.group)  # the ONE collective of the path
             out = merge_topk_packed(gathered, nq, self.world, k, self.metric_type)
             done = torch.cuda.Event()
             done.record(side)
-        return ShardedMipsIndex._Pending(out, done, (packed, gathered), self.local)
+        return ShardedMipsIndex._Pending(out, done, (packed, gathered, q), self.local)
 
     # ------------------------------------------------------------------ search
     def search(self, q, k: int, idx_offset: int = 0, force_ip: bool = False):

@@ -1493,3 +1493,36 @@ def test_pitch_1024_k_split_kernel_is_bit_identical():
     s, i = ix.search(ql, 5)
     es, ei = orc.search_exact_bruteforce(ql, x, 5)
     assert np.array_equal(i, ei) and np.array_equal(s, es) and "scan_kernel_ks" in ix.last_kernel
+
+
+def test_split_tail_searches_overlap_without_sharing_scratch():
+    """mips_search_split: scan on the current stream, select + exact re-score on a side stream, two alternating scratch
+    sets.  A train of back-to-back searches with DIFFERENT queries and shapes (no synchronisation in between, plain
+    searches interleaved) returns exactly what the same searches return one at a time."""
+    ix = ram.MipsIndex(768)
+    ix.add_synthetic(150001, 0, synth.SEED_DOCS, synth.KIND_GAUSS)
+    side = torch.cuda.Stream()
+    qs = [ram.synth_fill(n, 768, 0, 500 + t, synth.KIND_GAUSS) for t, n in enumerate((700, 300, 4096, 8, 513, 700, 100, 1024))]
+    refs = [ix.search(q, 5, 1000) for q in qs]
+    torch.cuda.synchronize()
+    outs = []
+    for t, q in enumerate(qs):
+        if t == 4:
+            outs.append(ix.search(q, 5, 1000))                       # a plain search in the middle of the train
+        else:
+            outs.append(ix.search(q, 5, 1000, tail_stream=side))
+    packed = ix.search_packed(qs[0], 5, 1000, tail_stream=side)
+    side.synchronize()
+    torch.cuda.synchronize()
+    ix.check()
+    for (s, i), (rs, ri) in zip(outs, refs):
+        assert torch.equal(i, ri) and torch.equal(s, rs)
+    assert torch.equal(packed[..., 1], refs[0][1])
+    # ShardedMipsIndex.search_async without a process group: the same overlap for consecutive batches on one GPU
+    sh = ram.ShardedMipsIndex(768)
+    sh.add_synthetic_global(150001, synth.SEED_DOCS, synth.KIND_GAUSS)
+    pend = [sh.search_async(q, 5) for q in qs]
+    for p_, (rs, ri) in zip(pend, refs):
+        s, i = p_.result()
+        torch.cuda.synchronize()
+        assert torch.equal(i, ri - 1000) and torch.equal(s, rs)
