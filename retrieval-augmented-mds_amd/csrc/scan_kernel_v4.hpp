@@ -40,7 +40,8 @@ __device__ __forceinline__ unsigned lane_id_here() {
     return ln;
 }
 
-template <int KL, int KS32, int AD, int TIMING_MODE = 0>
+// NT_DOCS: non-temporal document DMA -- for searches of ONE query tile, where every document block has a single reader
+template <int KL, int KS32, int AD, int TIMING_MODE = 0, bool NT_DOCS = false>
 __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WAVES = 8;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
         const unsigned lane_off0 = (ln >> 3) * (unsigned)row_bytes + (((ln & 7u) ^ ((ln >> 4) & 7u)) << 4);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + stage * STAGE_BYTES + pc * 1024), 16,
                                                  (rg & 1) ? (lane_off0 ^ 64u) : lane_off0,
-                                                 rg * 8 * (int)row_bytes + slab * 128, 0, 0);
+                                                 rg * 8 * (int)row_bytes + slab * 128, 0, NT_DOCS ? 2 : 0);
     };
     auto issue = [&](const unsigned char* blk_base, int stage) {
 #pragma unroll

@@ -429,6 +429,59 @@ class Mips:
         cols = dict(self.data) if self.data is not None else (shard_cols or {})
         self.embeddings = KnowledgeBase(cols, index, self.index_name)
 
+    # ---- streaming form: CLS vectors go into the index AS THE ENCODER PRODUCES THEM, no Arrow-on-disk
+    # exchange (mips.py:243-244, 292-295), no second pass: max-norm is a running maximum, the IP normalisation is per
+    # row, phi is taken from the finished index -- the result is bit-identical to build_index(all rows at once)
+    def begin_index_build(self, d: int) -> None:
+        if self.string_factory not in (None, "Flat"):
+            raise NotImplementedError(
+                f"mips_string_factory={self.string_factory!r}: only the exact 'Flat' index is implemented")
+        self._building = {"index": MipsIndex(int(d), metric=self.metric_type, dtype=self.args.mips_index_dtype,
+                                             device=self.args.mips_device),
+                          "max_sq": 0.0, "cols": {}, "rows": 0}
+
+    def add_embeddings(self, batch, columns: dict = None) -> None:
+        """One encoder batch: float32 [n, d] (CUDA tensor straight from the encoder, or NumPy) + its slice of the
+        text / id columns.  Honours mips_db_max_size like the one-shot build."""
+        import torch
+
+        b = getattr(self, "_building", None)
+        if b is None:
+            raise RuntimeError("add_embeddings: call begin_index_build(d) first")
+        dev = f"cuda:{_lib.require_gpu(self.args.mips_device)}"
+        x = torch.as_tensor(batch)
+        if isinstance(self.args.mips_db_max_size, int):
+            room = max(0, self.args.mips_db_max_size - b["rows"])
+            x = x[:room]
+            if columns is not None:
+                columns = {c: list(v)[:room] for c, v in columns.items()}
+        if x.shape[0] == 0:
+            return
+        y = x.to(dev, dtype=torch.float32).contiguous()
+        if isinstance(batch, torch.Tensor) and y.data_ptr() == batch.data_ptr():
+            y = y.clone()  # the normalisation below is in place; never touch the encoder's tensor
+        b["max_sq"] = max(b["max_sq"], rows_max_sumsq(y))
+        if self.normalize and self.metric_type == METRIC_INNER_PRODUCT:
+            l2_normalize_(y)
+        b["index"].add(y)
+        b["rows"] += int(y.shape[0])
+        for c, v in (columns or {}).items():
+            b["cols"].setdefault(c, []).extend(list(v))
+
+    def end_index_build(self) -> None:
+        b = getattr(self, "_building", None)
+        if b is None:
+            raise RuntimeError("end_index_build: no build in progress")
+        self._building = None
+        self.max_norm = float(np.sqrt(b["max_sq"]))
+        index = b["index"]
+        if self.metric_type == METRIC_L2 and index.ntotal > 0:
+            self.phi = index.phi()
+        if isinstance(self.args.mips_nprobe, int):
+            index.nprobe = self.args.mips_nprobe
+        cols = b["cols"] if b["cols"] else (dict(self.data) if self.data is not None else {})
+        self.embeddings = KnowledgeBase(cols, index, self.index_name)
+
     def build_index_sharded(self, embeddings) -> None:
         """Collective form of build_index for mips_shard=True: EVERY rank passes the full [N, d] matrix (array or
         memory map) and keeps rows [r * ceil(N / G), ...) only; max_norm and phi are all-reduced (MAX) so every

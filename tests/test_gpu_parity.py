@@ -1526,3 +1526,35 @@ def test_split_tail_searches_overlap_without_sharing_scratch():
         s, i = p_.result()
         torch.cuda.synchronize()
         assert torch.equal(i, ri - 1000) and torch.equal(s, rs)
+
+
+@pytest.mark.parametrize("metric,normalize", [(0, True), (1, True), (0, False)])
+def test_streaming_index_build_equals_one_shot_build(tmp_path, metric, normalize):
+    """begin_index_build / add_embeddings (encoder batches, CUDA or NumPy, with their text columns) /
+    end_index_build give the index, max_norm and phi of build_index on the whole matrix, bit for bit."""
+    n, d, k = 7003, 768, 5
+    rng = np.random.default_rng(21)
+    emb = (synth.generate(271, 0, n, d, synth.KIND_GAUSS) * rng.uniform(0.4, 2.5, (n, 1))).astype(np.float32)
+    qs = synth.generate(272, 0, 9, d, synth.KIND_GAUSS)
+    data = {"mips_column": [f"text {t}" for t in range(n)], "aid": [f"a{t}" for t in range(n)]}
+    args = ram.MipsArgs(mips_metric_type=metric, mips_normalize=normalize, mips_tmp_folder=str(tmp_path), mips_db_max_size=6500)
+    one = ram.Mips(args, data=data)
+    one.build_index(emb)
+    st = ram.Mips(args)
+    st.begin_index_build(d)
+    cuts = [0, 1000, 1001, 2500, 6400, 6900, n]                   # the last batches cross mips_db_max_size
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        batch = torch.from_numpy(emb[a:b]).cuda() if (a // 1000) % 2 == 0 else emb[a:b]
+        keep = batch.clone() if isinstance(batch, torch.Tensor) else None
+        st.add_embeddings(batch, {c: v[a:b] for c, v in data.items()})
+        assert keep is None or torch.equal(batch, keep)            # the encoder's tensor is left alone
+    st.end_index_build()
+    i1, i2 = one._index(), st._index()
+    assert i2.ntotal == i1.ntotal == 6500 and np.array_equal(i1.rows_bf16(), i2.rows_bf16())
+    assert st.max_norm == one.max_norm and st.phi == one.phi
+    assert st.embeddings.columns["aid"] == data["aid"][:6500]
+    pq = one._prepare_query(qs.copy())
+    s1, j1 = one.search(pq, k=k)
+    s2, j2 = st.search(pq, k=k)
+    assert np.array_equal(j1, j2) and np.array_equal(s1, s2)
+    assert st.forward(qs.copy(), k=k).examples == one.forward(qs.copy(), k=k).examples
