@@ -393,9 +393,11 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     const int wg_target = variant == 1 ? 512 : 256;                   // resident workgroups on 256 CUs
     const int64_t nq_pad = round_up(nq, kQueryAlign);
     const int nqt = (int)((nq + tn - 1) / tn);
-    // one query tile: scan_kernel_v3 with non-temporal DMA up to 160 queries (HBM-bound: 4.21 vs 4.62 ms at Q = 128 on
-    // 2^24 rows), the 16x16x32 kernel beyond (5.75 vs 5.99 ms at Q = 256: six to eight waves multiply, its higher clock pays)
-    const bool want_v4 = !want_v5 && (v4_forced || (v4_auto && (nqt > 1 || nq > 160)));
+    // One query tile (round 2): with non-temporal document DMA the 16x16x32 kernel ties scan_kernel_v3 in the HBM-bound
+    // regime on large indexes (3.80 vs 3.82 ms at Q = 64 on 2^24 rows), loses 3-8 % on short streams at Q = 8 (0.315 vs
+    // 0.304 ms at 2^20 rows, 0.091 vs 0.084 at 2^17) and wins once several waves multiply (3.89 vs 4.15 ms at Q = 128,
+    // 5.57 vs 5.98 at Q = 256; profiles/r2_final/ab_single_tile.md): scan_kernel_v3 up to 64 queries, v4 beyond
+    const bool want_v4 = !want_v5 && (v4_forced || (v4_auto && (nqt > 1 || nq > 64)));
     // scan_kernel_ks (K split over a wave pair, two waves per SIMD): row pitch 1024, k <= 5.  Selectable ("variant" =
     // 6), not the default: measured 30.6 vs 31.3 ms at 2^22 x 1024 against the one-wave-per-SIMD scan_kernel_v3
     // configuration (profiles/r2_pitch1024) -- both sit on the L2 -> LDS fill of 128 stationary queries per CU
@@ -520,17 +522,17 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
                 return MIPS_OK;
             };
             int rc2;
+            const bool nt = nqt == 1 && ix->opt_sub != 30; // one query tile: every document block has a single reader
 #ifdef MIPS_EXPERIMENTAL
             if (ix->ld == 768 && ix->opt_sub == 8) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 1>); // timing only: no epilogue
             else
 #endif
-            if (ix->ld == 768 && nqt == 1 && ix->opt_sub != 30) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 0, true>);
-            else if (ix->ld == 768) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2>);
-            else if (ix->ld == 640) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 20, 2>);
-            else if (ix->ld == 512) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 16, 2>);
-            else rc2 = go4(mips::scan_kernel_v4<V4_KLL, 12, 2>);
+            if (ix->ld == 768) rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 0, true>) : go4(mips::scan_kernel_v4<V4_KLL, 24, 2>);
+            else if (ix->ld == 640) rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 20, 2, 0, true>) : go4(mips::scan_kernel_v4<V4_KLL, 20, 2>);
+            else if (ix->ld == 512) rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 16, 2, 0, true>) : go4(mips::scan_kernel_v4<V4_KLL, 16, 2>);
+            else rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 12, 2, 0, true>) : go4(mips::scan_kernel_v4<V4_KLL, 12, 2>);
             if (rc2) return rc2;
-            set_kernel_name(ix, ix->ld == 768 && nqt == 1 && ix->opt_sub != 30 ? "mips::scan_kernel_v4<%d, %d, 2, 0, true>" : "mips::scan_kernel_v4<%d, %d, 2, 0, false>", V4_KLL, ix->ld / 32);
+            set_kernel_name(ix, nt ? "mips::scan_kernel_v4<%d, %d, 2, 0, true>" : "mips::scan_kernel_v4<%d, %d, 2, 0, false>", V4_KLL, ix->ld / 32);
         }
     } else if (want_f8x) {
         if constexpr (KL == 8) {
