@@ -172,8 +172,9 @@ int mips_search_split(mips_index_t* index, const void* q, int q_dtype, int64_t n
  *   buffer is NOT modified; ignore_device [nq] int64 or NULL; out_scores / out_idx DEVICE [nq, k].
  * For the reference's own call shape (nq <= 16, bf16 index of <= 65536 rows, k + 1 <= 6) all of it is ONE kernel launch
  * (csrc/tiny_search.hpp: staging, MFMA scan, select, exact re-score, filter); other shapes run the same steps as
- * separate launches.  Results are identical either way ("tiny" = 0 in mips_index_set_param forces the general path;
- * mips_search takes the one-launch kernel for eligible shapes as well). */
+ * separate launches.  Results are identical either way ("tiny" = 0 in mips_index_set_param forces the general path,
+ * "tiny" = 2 the one-launch kernel with its fall-back selection and sequential re-score -- test knobs; mips_search
+ * takes the one-launch kernel for eligible shapes as well). */
 int mips_search_fused(mips_index_t* index, const void* q_device, int q_dtype, int64_t nq, int k, int normalize,
                       const int64_t* ignore_device, float* out_scores_device, int64_t* out_idx_device,
                       int64_t idx_offset, void* hip_stream);

@@ -486,60 +486,11 @@ __global__ __launch_bounds__(64) void merge_select_kernel(MergeArgs p, int* cand
     merge_select_body<KL>(p, cand, (int)blockIdx.x, (int)threadIdx.x);
 }
 
-template <int KL, typename EL, bool L2>
-__device__ __forceinline__ void rescore_rank_body(const MergeArgs& p, const int* cand, int64_t nq, int64_t wave_index, int lane) {
-    constexpr int QPW = 64 / KL; // queries per wave
-    const int64_t q = wave_index * QPW + lane / KL;
-    const int slot = lane % KL;
-    const bool inq = q < nq && lane < QPW * KL; // K' = 10: lanes 60..63 belong to no query
-    if (p.err != nullptr && *p.err != 0u) { // the scan gave up on its barrier: nothing below can be trusted
-        if (wave_index == 0 && lane == 0) __hip_atomic_store(p.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (inq && slot < p.k) {
-            const size_t o = (size_t)q * p.k + slot;
-            if (p.out_packed) {
-                p.out_packed[2 * o] = (int64_t)__float_as_uint(poison_score());
-                p.out_packed[2 * o + 1] = IDX_POISON;
-            } else {
-                p.out_s[o] = poison_score();
-                p.out_i[o] = IDX_POISON;
-            }
-        }
-        return;
-    }
-    const int ci = inq ? cand[(size_t)q * KL + slot] : IDX_NONE;
-    const bool valid = ci != IDX_NONE;
-    double dot = 0.0, qq = 0.0;
-    if (valid) {
-        const typename EL::type* x = reinterpret_cast<const typename EL::type*>(p.docs) + (size_t)ci * p.ld;
-        const typename EL::type* y = reinterpret_cast<const typename EL::type*>(p.qbuf) + (size_t)q * p.ld;
-        constexpr int PF = 24; // 16-byte chunks in flight per row: the kernel is one latency-bound thread per candidate
-        const int nchunk = p.ld / EL::PER16;
-        u32x4 xr[PF], yr[PF];
-#pragma unroll
-        for (int t = 0; t < PF; ++t) {
-            const int c = t < nchunk ? t : nchunk - 1;
-            xr[t] = *reinterpret_cast<const u32x4*>(x + c * EL::PER16);
-            yr[t] = *reinterpret_cast<const u32x4*>(y + c * EL::PER16);
-        }
-        for (int c0 = 0; c0 < nchunk; c0 += PF) {
-#pragma unroll
-            for (int t = 0; t < PF; ++t) {
-                const u32x4 xv = xr[t], yv = yr[t];
-                const int nx = c0 + PF + t < nchunk ? c0 + PF + t : nchunk - 1;
-                xr[t] = *reinterpret_cast<const u32x4*>(x + nx * EL::PER16);
-                yr[t] = *reinterpret_cast<const u32x4*>(y + nx * EL::PER16);
-                if (c0 + t < nchunk) {
-#pragma unroll
-                    for (int e = 0; e < EL::PER16; ++e) {
-                        const double xe = (double)EL::get(xv, e);
-                        const double ye = (double)EL::get(yv, e);
-                        dot += xe * ye;
-                        qq += ye * ye; // |q|^2: L2 distances and the margin check
-                    }
-                }
-            }
-        }
-    }
+// Steps 4 + margin check of the re-score, shared by rescore_rank_body and tiny_search.hpp: lane (q, slot) holds candidate ci
+// of query q with its canonical dot product and |q|^2 (fp64); rank inside the query's KL-lane group, flag, write.
+template <int KL, bool L2>
+__device__ __forceinline__ void rank_flag_write(const MergeArgs& p, int64_t q, int slot, bool inq, int ci, bool valid, double dot, double qq,
+                                                int lane) {
     float outv, key;
     if (L2) { // L2 on phi-augmented vectors: |q|^2 + phi - 2 q.x, smaller is better
         outv = (float)(qq + p.phi - 2.0 * dot);
@@ -615,6 +566,63 @@ __device__ __forceinline__ void rescore_rank_body(const MergeArgs& p, const int*
             p.out_i[o] = -1;
         }
     }
+}
+
+template <int KL, typename EL, bool L2>
+__device__ __forceinline__ void rescore_rank_body(const MergeArgs& p, const int* cand, int64_t nq, int64_t wave_index, int lane) {
+    constexpr int QPW = 64 / KL; // queries per wave
+    const int64_t q = wave_index * QPW + lane / KL;
+    const int slot = lane % KL;
+    const bool inq = q < nq && lane < QPW * KL; // K' = 10: lanes 60..63 belong to no query
+    if (p.err != nullptr && *p.err != 0u) { // the scan gave up on its barrier: nothing below can be trusted
+        if (wave_index == 0 && lane == 0) __hip_atomic_store(p.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (inq && slot < p.k) {
+            const size_t o = (size_t)q * p.k + slot;
+            if (p.out_packed) {
+                p.out_packed[2 * o] = (int64_t)__float_as_uint(poison_score());
+                p.out_packed[2 * o + 1] = IDX_POISON;
+            } else {
+                p.out_s[o] = poison_score();
+                p.out_i[o] = IDX_POISON;
+            }
+        }
+        return;
+    }
+    const int ci = inq ? cand[(size_t)q * KL + slot] : IDX_NONE;
+    const bool valid = ci != IDX_NONE;
+    double dot = 0.0, qq = 0.0;
+    if (valid) {
+        const typename EL::type* x = reinterpret_cast<const typename EL::type*>(p.docs) + (size_t)ci * p.ld;
+        const typename EL::type* y = reinterpret_cast<const typename EL::type*>(p.qbuf) + (size_t)q * p.ld;
+        constexpr int PF = 24; // 16-byte chunks in flight per row: the kernel is one latency-bound thread per candidate
+        const int nchunk = p.ld / EL::PER16;
+        u32x4 xr[PF], yr[PF];
+#pragma unroll
+        for (int t = 0; t < PF; ++t) {
+            const int c = t < nchunk ? t : nchunk - 1;
+            xr[t] = *reinterpret_cast<const u32x4*>(x + c * EL::PER16);
+            yr[t] = *reinterpret_cast<const u32x4*>(y + c * EL::PER16);
+        }
+        for (int c0 = 0; c0 < nchunk; c0 += PF) {
+#pragma unroll
+            for (int t = 0; t < PF; ++t) {
+                const u32x4 xv = xr[t], yv = yr[t];
+                const int nx = c0 + PF + t < nchunk ? c0 + PF + t : nchunk - 1;
+                xr[t] = *reinterpret_cast<const u32x4*>(x + nx * EL::PER16);
+                yr[t] = *reinterpret_cast<const u32x4*>(y + nx * EL::PER16);
+                if (c0 + t < nchunk) {
+#pragma unroll
+                    for (int e = 0; e < EL::PER16; ++e) {
+                        const double xe = (double)EL::get(xv, e);
+                        const double ye = (double)EL::get(yv, e);
+                        dot += xe * ye;
+                        qq += ye * ye; // |q|^2: L2 distances and the margin check
+                    }
+                }
+            }
+        }
+    }
+    rank_flag_write<KL, L2>(p, q, slot, inq, ci, valid, dot, qq, lane);
 }
 
 template <int KL, typename EL, bool L2>

@@ -9,6 +9,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
+#include <cstdlib>
 
 #include "../../include/mips_hip.h"
 #include "aux_kernels.hpp"
@@ -738,7 +740,9 @@ int tiny_search(mips_index* ix, const void* q_dev, int q_dtype, int64_t nq, int 
         HIP_TRY(hipMemsetAsync(ix->tiny_words, 0, 64, st)); // the ticket starts at 0; the kernel's last workgroup resets it
     }
     const int ntiles = (int)((ix->ntotal + 15) / 16);
-    const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>(128, (ntiles + 7) / 8));
+    // one tile per wave, 8 waves per workgroup, while the chip has the CUs for it (more workgroups = more candidates for
+    // the last one to sift; spreading thinner did not make the first tiles arrive sooner)
+    const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>(mips::TINY_MAX_WG, (ntiles + mips::TINY_WAVES - 1) / mips::TINY_WAVES));
     mips::TinyArgs a;
     a.docs = (const uint16_t*)ix->rows;
     a.q = q_dev;
@@ -749,7 +753,8 @@ int tiny_search(mips_index* ix, const void* q_dev, int q_dtype, int64_t nq, int 
     a.ld = ix->ld;
     a.ntotal = ix->ntotal;
     a.ntiles = ntiles;
-    a.nwaves = nwg * 4;
+    a.nwaves = nwg * mips::TINY_WAVES;
+    a.force_slow = ix->opt_tiny == 2 ? 1 : 0;
     a.ticket = ix->tiny_words;
     a.ignore = ignore_dev;
     a.k_out = k_out;
@@ -802,10 +807,41 @@ int tiny_search(mips_index* ix, const void* q_dev, int q_dtype, int64_t nq, int 
         m.nflag = ix->tiny_words + 1;
         ix->last_nflag_dev = m.nflag;
     }
-    const int lds = 16 * ix->ld * 2 + 2 * 16 * 96 * 4 + 3 * 512 + 16 * 8 * 8;
-    if (ix->call_metric == MIPS_METRIC_L2) mips::tiny_search_kernel<true><<<nwg, 256, lds, st>>>(a);
-    else mips::tiny_search_kernel<false><<<nwg, 256, lds, st>>>(a);
+    const int lds = mips::tiny_lds_bytes(ix->ld);
+#ifdef MIPS_EXPERIMENTAL
+    static unsigned long long* dbg_dev = nullptr;
+    const bool dbg = getenv("MIPS_TINY_DBG") != nullptr;
+    if (dbg && !dbg_dev) HIP_TRY(hipMalloc((void**)&dbg_dev, 256 * 16 * 8));
+    a.dbg = dbg ? dbg_dev : nullptr;
+    if (dbg) HIP_TRY(hipMemsetAsync(dbg_dev, 0, 256 * 16 * 8, st));
+#endif
+    if (lds > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void*)mips::tiny_search_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)mips::tiny_search_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    if (ix->call_metric == MIPS_METRIC_L2) mips::tiny_search_kernel<true><<<nwg, mips::TINY_THREADS, lds, st>>>(a);
+    else mips::tiny_search_kernel<false><<<nwg, mips::TINY_THREADS, lds, st>>>(a);
     HIP_TRY(hipGetLastError());
+#ifdef MIPS_EXPERIMENTAL
+    if (dbg) { // phase stamps (10 ns units) relative to the first workgroup's start: the slowest workgroup per phase and the last one
+        std::vector<unsigned long long> h(256 * 16);
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(h.data(), dbg_dev, 256 * 16 * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        int last = 0;
+        for (int b = 0; b < nwg; ++b) {
+            t0 = std::min(t0, h[b * 16]);
+            if (h[b * 16 + 11]) last = b;
+        }
+        unsigned long long mx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < nwg; ++b)
+            for (int i = 0; i < 8; ++i) mx[i] = std::max(mx[i], h[b * 16 + i] - t0);
+        fprintf(stderr, "tiny x10ns max/%d wgs: start %llu docs-issued %llu zero-rows %llu rows-staged %llu barrier %llu scanned %llu selected %llu ticket %llu | last wg %d: ticket %llu select2 %llu dots %llu ranked %llu end %llu | shader clock %.0f MHz\n",
+                nwg, mx[0], mx[1], mx[2], mx[3], mx[4], mx[5], mx[6], mx[7], last, h[last * 16 + 7] - t0, h[last * 16 + 8] - t0,
+                h[last * 16 + 9] - t0, h[last * 16 + 10] - t0, h[last * 16 + 11] - t0,
+                (double)(h[last * 16 + 13] - h[last * 16 + 12]) / ((double)(h[last * 16 + 11] - h[last * 16]) * 0.01));
+    }
+#endif
     set_kernel_name(ix, "mips::tiny_search_kernel<%s>", ix->call_metric == MIPS_METRIC_L2 ? "true" : "false");
     return MIPS_OK;
 }
@@ -1486,7 +1522,7 @@ int mips_index_set_param(mips_index_t* ix, const char* name, int64_t value) {
     if (n == "nsplit") ix->opt_nsplit = (int)value;
     else if (n == "qgroups") ix->opt_qgroups = (int)value;
     else if (n == "variant") ix->opt_variant = (int)value;
-    else if (n == "tiny") ix->opt_tiny = value != 0 ? 1 : 0;
+    else if (n == "tiny") ix->opt_tiny = value == 2 ? 2 : value != 0 ? 1 : 0; // 2: one launch, fall-back paths forced (tests)
     else if (n == "margin_check") {
         if (value < 0 || value > 2) return fail(MIPS_E_INVALID, "mips_index_set_param: margin_check must be 0, 1 or 2");
         ix->opt_margin = (int)value;

@@ -1433,6 +1433,40 @@ def test_tiny_search_ties_and_stream_of_calls():
     assert np.array_equal(i.cpu().numpy(), ei)
 
 
+@pytest.mark.parametrize("metric", [0, 1])
+def test_tiny_search_fallback_paths(metric):
+    """tiny_search_kernel's fast selection (threshold + rank by counting) hands over to the pop selection when more than
+    64 candidates tie at the threshold, and its parallel exact re-score to the sequential sum when the products' exponent
+    range is too wide for the exactness certificate: both must return the oracle's bits; "tiny" = 2 forces the
+    fall-backs everywhere and must agree too."""
+    rng = np.random.default_rng(77)
+    # (1) thousands of identical rows: every list head ties, > 64 survivors at both selection levels
+    x = synth.generate(301, 0, 6000, 768, synth.KIND_GAUSS)
+    x[100:5100] = x[100]
+    q = synth.generate(302, 0, 8, 768, synth.KIND_GAUSS)
+    q[0] = x[100]
+    # (2) rows and queries with elements down to 2^-60 next to O(1) ones: exponent range of the products > 27
+    y = synth.generate(303, 0, 4000, 768, synth.KIND_GAUSS)
+    scale = np.where(rng.random((4000, 768)) < 0.05, np.float32(2.0 ** -60), np.float32(1.0)).astype(np.float32)
+    y = (y * scale).astype(np.float32)
+    qy = synth.generate(304, 0, 12, 768, synth.KIND_GAUSS)
+    qy[:, ::7] *= np.float32(2.0 ** -40)
+    for data, qq in ((x, q), (y, qy)):
+        ix = _index(data, metric=metric)
+        stored = synth.bf16_bits_to_f32(ix.rows_bf16())
+        qb = synth.round_to_bf16(qq)                                # the queries are rounded to the index's bf16 (RNE)
+        es, ei = orc.search_exact_bruteforce(qb, stored, 5, metric=metric)   # (thousands of exact ties: the plain definition)
+        qd = torch.from_numpy(qq).cuda()                           # device outputs: flagged queries are counted, not re-scanned
+        for mode in (1, 2):
+            ix.set_param("tiny", mode)
+            s, i = ix.search(qd, 5)
+            assert ix.last_kernel.startswith("mips::tiny_search_kernel")
+            assert np.array_equal(i.cpu().numpy(), ei) and np.array_equal(s.cpu().numpy(), es), (mode, metric)
+        ix.set_param("tiny", 0)
+        s, i = ix.search(qq, 5)
+        assert np.array_equal(i, ei) and np.array_equal(s, es)
+
+
 @pytest.mark.parametrize("metric,normalize", [(0, True), (0, False), (1, True)])
 def test_fused_hook_search_prepare_search_ignore_in_one_call(tmp_path, metric, normalize):
     """Mips.search_device -> mips_search_fused: `_prepare_query` + `search` + the ignore filter of mips.py:388-398 as
