@@ -93,7 +93,12 @@ const char* mips_last_error(void);
  *   MIPS_DTYPE_BF16      2 B/element, inputs rounded to bf16 (RNE); the fast path
  *   MIPS_DTYPE_FP8_E4M3  1 B/element, inputs AND queries rounded to OCP e4m3 (d <= 1024, k <= 13)
  *   MIPS_DTYPE_F32       fp32-exact: results are those of an fp32 brute force on the caller's values
- *                        (bf16 hi|lo planes for the scan + the fp32 rows for the exact re-score, 8 B/element). */
+ *                        (bf16 hi|lo planes for the three-segment scan + the fp32 rows for the exact re-score, 8 B/element;
+ *                        for d <= 1024 also bf16(x) alone at the fast kernels' row pitch, + 2 B/element: searches with
+ *                        k <= 7 that may synchronise (host buffers, or "margin_check" = 2) scan THAT like a bf16 index,
+ *                        re-score on the fp32 rows, and send only the queries whose margin -- widened by the
+ *                        representation error |x - bf16 x| |q| + |bf16 x| |q - bf16 q| -- is not certified through the
+ *                        three-segment scan: same results, ~3x the rate on well-separated data; "f32_fast" below). */
 int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, int metric);
 
 /* Free the index and its scratch.  Replaces Dataset.drop_index (mips.py:537). */
@@ -238,7 +243,9 @@ int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out
  * register-staged tiles, 3 = query-stationary on the 32x32x16 MFMA shape, 4 = query-stationary on the
  * 16x16x32 shape (d padding to 384 .. 768, k <= 5)).  Results never depend on these four; only speed does.
  * "margin_check" (0 / 1 / 2) selects what happens to queries whose candidate pool is not provably wide enough: see
- * mips_index_margin_stats.
+ * mips_index_margin_stats.  "f32_fast" (fp32-exact index): 0 = always the three-segment scan, 1 (default) = two-stage search
+ * when the call may synchronise, skipped for 8 calls after one that sent more than a quarter of its queries to the second
+ * stage, 2 = two-stage always (device-output searches then only COUNT the uncertified queries, like every margin check).
  * Two more names exist for tests and experiments and are NOT tuning knobs:
  *   "spin_limit"  polls a wave spends on the scan's block barrier before it gives up (0 = the shipped 2^22).  A tiny
  *                 value makes the kernel give up spuriously and -1 makes every scan launch raise its error word

@@ -291,6 +291,43 @@ __global__ void row_sumsq_max_kernel(const typename EL::type* rows, int64_t n, i
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(acc));
 }
 
+// max_i |x_i - bf16(x_i)|^2 over fp32 rows (two-stage fp32-exact search: how far the bf16 scan's operand is from the row)
+__global__ void row_resid_sumsq_max_kernel(const float* rows, int64_t n, int ld, unsigned long long* out_bits) {
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    double acc = 0.0;
+    if (r < n) {
+        const float* x = rows + r * ld;
+        for (int c = 0; c < ld; c += 4) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(x + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xe = __uint_as_float(v[e]);
+                const double a = (double)xe - (double)bf16_bits_to_f32(f32_to_bf16_rne(xe));
+                acc += a * a;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc = fmax(acc, __shfl_xor(acc, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(acc));
+}
+
+// |q - bf16(q)|^2 per staged fp32 query row (one wave per row)
+__global__ __launch_bounds__(256) void query_resid_kernel(const float* q, int64_t nq, int ld, double* out) {
+    const int64_t row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= nq) return;
+    double acc = 0.0;
+    for (int c = lane; c < ld; c += 64) {
+        const float xe = q[row * ld + c];
+        const double a = (double)xe - (double)bf16_bits_to_f32(f32_to_bf16_rne(xe));
+        acc += a * a;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) out[row] = acc * (1.0 + 1e-12); // (a bound: the summation order is free)
+}
+
 // ------------------------------------------------------------------ row L2 normalisation (fp32, in place)
 // Replaces faiss.normalize_L2 as used by Mips.l2_normalization (sotasum/mips.py:521-525; faiss
 // fvec_renorm_L2: nr = sum x^2 in fp32, x *= 1/sqrtf(nr) when nr > 0).  One wave per row.
@@ -372,6 +409,10 @@ struct MergeArgs {
     unsigned* nflag;      // device counter of flagged queries of this call (nullptr: margin check off)
     const double* xmax2;  // device scalar: max_i |x_i|^2 over the stored rows
     double err_c;         // MFMA score error <= err_c * |q| * |x|   (d * 2^-23: fp32 accumulation of exact products)
+    // two-stage fp32-exact search (mips_hip.hip, "f32_fast"): the scan saw bf16(x) . bf16(q) only; the exact score differs
+    // from that by at most |x - bf16 x| |q| + |bf16 x| |q - bf16 q|  (Cauchy-Schwarz), added to the margin
+    const double* dres2 = nullptr; // device scalar: max_i |x_i - bf16(x_i)|^2 over the stored rows
+    const double* qerr2 = nullptr; // [nq]: |q - bf16(q)|^2
 };
 
 // What a search whose scan kernel gave up (split-barrier spin bound, scan_kernel_v3.hpp) returns instead of
@@ -537,7 +578,11 @@ __device__ __forceinline__ void rank_flag_write(const MergeArgs& p, int64_t q, i
             const float b = p.bnd[q];
             bool fl = false;
             if (have && b > -INFINITY) {
-                const double e = p.err_c * sqrt(qn) * sqrt(*p.xmax2);
+                double e = p.err_c * sqrt(qn) * sqrt(*p.xmax2);
+                if (p.qerr2 != nullptr) {
+                    const double dr = sqrt(*p.dres2);
+                    e += dr * sqrt(qn) + (sqrt(*p.xmax2) + dr) * sqrt(p.qerr2[q]);
+                }
                 fl = !((double)b + e < tk); // also true for NaN: never certify what cannot be compared
             }
             p.flag[q] = fl ? 1 : 0;

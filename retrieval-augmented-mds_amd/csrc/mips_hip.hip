@@ -107,6 +107,19 @@ struct mips_index {
     // rows_f32 = the fp32 originals [capacity][plane] for the exact re-score; qf32 = staged fp32 queries
     int plane = 0;
     float* rows_f32 = nullptr;
+    // two-stage search of the fp32-exact index ("f32_fast", d <= 1024): rows_hi = bf16(x) alone at a row pitch the
+    // query-stationary kernels take ([capacity][hp]; converted lazily from rows_f32 up to hi_rows).  Stage 1 scans it
+    // like a bf16 index and re-scores on the fp32 rows; the margin check, widened by the representation error
+    // |x - bf16 x| |q| + |bf16 x| |q - bf16 q|, sends the queries it cannot certify to the three-segment scan.
+    uint8_t* rows_hi = nullptr;
+    int hp = 0;
+    int64_t hi_rows = 0;
+    double* dres2_dev = nullptr; // max_i |x_i - bf16 x_i|^2
+    bool dres2_valid = false;
+    int opt_f32_fast = 1;        // 0 off, 1 when the call may synchronise (host buffers / margin_check = 2), 2 always
+    bool fast_f32 = false;       // launch_search: stage 1 in progress (index viewed as bf16 rows_hi)
+    int plane_keep = 0;
+    int fast_skip = 0;           // calls left to skip stage 1 for (the last one flagged too many queries to pay)
     bool phi_valid = false;
     int call_metric = MIPS_METRIC_IP; // metric of the search in progress (index metric unless MIPS_FORCE_IP)
     bool phi_override = false; // phi was set from outside (global maximum of a sharded index): adds do not reset it
@@ -129,7 +142,7 @@ struct mips_index {
     // synchronise, re-scan the flagged queries with the widest lists.  Host-output searches always certify (they
     // synchronise anyway) unless the check is off.
     int opt_margin = 1;
-    Buffer mbnd, mflag, qbuf2, qf32b, tmp_s, tmp_i, ids;
+    Buffer mbnd, mflag, qbuf2, qf32b, tmp_s, tmp_i, ids, qhi, qerr2;
     double* xmax2_dev = nullptr; // max_i |x_i|^2 of the LOCAL rows, on the device (no host copy: never synchronises)
     bool xmax2_valid = false;
     unsigned* nflag_host = nullptr; // pinned: flagged-query count of the last certified search
@@ -206,6 +219,7 @@ int grow(mips_index* ix, int64_t need_rows, hipStream_t st, bool exact = false) 
     cap = round_up(cap, kRowAlign);
     uint8_t* fresh = nullptr;
     float* fresh32 = nullptr;
+    uint8_t* fresh_hi = nullptr;
     const size_t row_bytes = (size_t)ix->ld * ix->esize;
     const size_t bytes = (size_t)cap * row_bytes;
     const size_t b32 = (size_t)cap * ix->plane * sizeof(float);
@@ -218,6 +232,15 @@ int grow(mips_index* ix, int64_t need_rows, hipStream_t st, bool exact = false) 
             return fail(MIPS_E_NOMEM, "hipMalloc(%zu) for the fp32 rows failed: %s", b32, hipGetErrorString(e));
         }
     }
+    const size_t bhi = (size_t)cap * ix->hp * 2;
+    if (ix->plane > 0 && ix->hp > 0) {
+        e = hipMalloc((void**)&fresh_hi, bhi);
+        if (e != hipSuccess) {
+            (void)hipFree(fresh);
+            (void)hipFree(fresh32);
+            return fail(MIPS_E_NOMEM, "hipMalloc(%zu) for the bf16 rows of the fp32 index failed: %s", bhi, hipGetErrorString(e));
+        }
+    }
     // copy the rows in use; rows past ntotal are read by the last (ragged) tile: keep them defined
     const size_t used = (size_t)ix->ntotal * row_bytes;
     const size_t u32 = (size_t)ix->ntotal * ix->plane * sizeof(float);
@@ -225,16 +248,22 @@ int grow(mips_index* ix, int64_t need_rows, hipStream_t st, bool exact = false) 
     if (e == hipSuccess) e = hipMemsetAsync(fresh + used, 0, bytes - used, st);
     if (e == hipSuccess && fresh32 && u32) e = hipMemcpyAsync(fresh32, ix->rows_f32, u32, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess && fresh32) e = hipMemsetAsync((char*)fresh32 + u32, 0, b32 - u32, st);
+    const size_t uhi = (size_t)ix->hi_rows * ix->hp * 2;
+    if (e == hipSuccess && fresh_hi && uhi) e = hipMemcpyAsync(fresh_hi, ix->rows_hi, uhi, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && fresh_hi) e = hipMemsetAsync(fresh_hi + uhi, 0, bhi - uhi, st);
     if (e == hipSuccess && ix->rows) e = hipStreamSynchronize(st); // the old storage is freed below
     if (e != hipSuccess) {
         (void)hipFree(fresh);
         if (fresh32) (void)hipFree(fresh32);
+        if (fresh_hi) (void)hipFree(fresh_hi);
         return fail(MIPS_E_HIP, "growing the index to %lld rows failed: %s", (long long)cap, hipGetErrorString(e));
     }
     if (ix->rows) (void)hipFree(ix->rows);
     if (ix->rows_f32) (void)hipFree(ix->rows_f32);
+    if (ix->rows_hi) (void)hipFree(ix->rows_hi);
     ix->rows = fresh;
     ix->rows_f32 = fresh32;
+    ix->rows_hi = fresh_hi;
     ix->capacity = cap;
     return MIPS_OK;
 }
@@ -337,6 +366,29 @@ int ensure_xmax2(mips_index* ix, hipStream_t st) {
         HIP_TRY(hipGetLastError());
     }
     ix->xmax2_valid = true;
+    return MIPS_OK;
+}
+
+// two-stage fp32-exact search: bf16 rows of the rows added since the last call, and the residual bound
+int ensure_hi(mips_index* ix, hipStream_t st) {
+    if (ix->hi_rows < ix->ntotal) {
+        const int64_t nr = ix->ntotal - ix->hi_rows;
+        const int64_t items = nr * (ix->hp / 8);
+        mips::convert_rows_kernel<float><<<grid_for(items, 256), 256, 0, st>>>(ix->rows_f32 + (size_t)ix->hi_rows * ix->plane, nr, ix->plane,
+                                                                               (uint16_t*)ix->rows_hi + (size_t)ix->hi_rows * ix->hp, ix->hp);
+        HIP_TRY(hipGetLastError());
+        ix->hi_rows = ix->ntotal;
+    }
+    if (!ix->dres2_valid) {
+        if (!ix->dres2_dev) HIP_TRY(hipMalloc((void**)&ix->dres2_dev, 8));
+        HIP_TRY(hipMemsetAsync(ix->dres2_dev, 0, 8, st));
+        if (ix->ntotal > 0) {
+            mips::row_resid_sumsq_max_kernel<<<(int)((ix->ntotal + 255) / 256), 256, 0, st>>>(ix->rows_f32, ix->ntotal, ix->plane,
+                                                                                             (unsigned long long*)ix->dres2_dev);
+            HIP_TRY(hipGetLastError());
+        }
+        ix->dres2_valid = true;
+    }
     return MIPS_OK;
 }
 
@@ -661,9 +713,10 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     m.part_s = a.part_s;
     m.part_i = a.part_i;
     m.ncand = (int)ncand;
-    m.docs = f32x ? (const void*)ix->rows_f32 : (const void*)ix->rows;
-    m.qbuf = f32x ? (const void*)ix->qf32.p : (const void*)a.qbuf;
-    m.ld = f32x ? ix->plane : ix->ld;
+    const bool f32r = f32x || ix->fast_f32; // exact re-score on the fp32 rows (stage 1 of the two-stage search included)
+    m.docs = f32r ? (const void*)ix->rows_f32 : (const void*)ix->rows;
+    m.qbuf = f32r ? (const void*)ix->qf32.p : (const void*)a.qbuf;
+    m.ld = ix->fast_f32 ? ix->plane_keep : f32x ? ix->plane : ix->ld;
     m.k = k;
     m.metric = ix->call_metric;
     m.phi = ix->phi;
@@ -684,6 +737,11 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // sum |q_j x_j| <= d 2^-23 |q| |x| (u = 2^-23 allows truncating adders).  fp32-exact mode scans hi.qhi + hi.qlo +
     // lo.qhi of bf16 splits: the dropped lo.qlo term adds 2^-16 |q| |x|, and there are three times the terms.
     m.err_c = f32x ? (3.0 * (double)ix->d * 1.1920928955078125e-07 + 1.52587890625e-05) : (double)ix->d * 1.1920928955078125e-07;
+    if (ix->fast_f32) { // the scan's operands are bf16(q), bf16(x): norms within 2^-8 of |q|, |x|
+        m.err_c *= 1.01;
+        m.dres2 = ix->dres2_dev;
+        m.qerr2 = (const double*)ix->qerr2.p;
+    }
     if (ix->opt_margin != 0) {
         rc = ix->mbnd.ensure((size_t)nq * sizeof(float));
         if (rc) return rc;
@@ -711,8 +769,8 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     HIP_TRY(hipGetLastError());
     const bool l2 = ix->call_metric == MIPS_METRIC_L2;
     const int rgrid = (int)((nq + (64 / KL) - 1) / (64 / KL));
-    if (f32x && l2) mips::rescore_rank_kernel<KL, mips::ElemF32, true><<<rgrid, 64, 0, st>>>(m, cand, nq);
-    else if (f32x) mips::rescore_rank_kernel<KL, mips::ElemF32, false><<<rgrid, 64, 0, st>>>(m, cand, nq);
+    if (f32r && l2) mips::rescore_rank_kernel<KL, mips::ElemF32, true><<<rgrid, 64, 0, st>>>(m, cand, nq);
+    else if (f32r) mips::rescore_rank_kernel<KL, mips::ElemF32, false><<<rgrid, 64, 0, st>>>(m, cand, nq);
     else if (f8 && l2) mips::rescore_rank_kernel<KL, mips::ElemF8, true><<<rgrid, 64, 0, st>>>(m, cand, nq);
     else if (f8) mips::rescore_rank_kernel<KL, mips::ElemF8, false><<<rgrid, 64, 0, st>>>(m, cand, nq);
     else if (l2) mips::rescore_rank_kernel<KL, mips::ElemBF16, true><<<rgrid, 64, 0, st>>>(m, cand, nq);
@@ -853,7 +911,7 @@ int tiny_search(mips_index* ix, const void* q_dev, int q_dtype, int64_t nq, int 
 // results.  Queries still flagged after that are counted as unresolved (mips_index_margin_stats).
 template <int KL>
 int finish_margin(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, bool packed, int64_t idx_offset, bool out_dev,
-                  hipStream_t st) {
+                  hipStream_t st, bool fast_first = false) {
     ix->last_flagged = -1;
     ix->last_rescanned = 0;
     ix->last_unresolved = 0;
@@ -867,7 +925,8 @@ int finish_margin(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, b
     if (n == 0) return MIPS_OK;
     constexpr int WIDE = 32;
     const bool f8 = ix->esize == 1;
-    const int wide = f8 ? (KL < 16 ? 16 : 0) : (KL < WIDE ? WIDE : 0);
+    // (fast_first: the scan just done was stage 1 of the two-stage fp32 search -- the re-scan is the three-segment scan)
+    const int wide = f8 ? (KL < 16 ? 16 : 0) : (KL < WIDE || fast_first ? WIDE : 0);
     if (wide == 0) { // already on the widest lists this storage type has
         ix->last_unresolved = n;
         return MIPS_OK;
@@ -936,6 +995,43 @@ int finish_margin(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, b
     return MIPS_OK;
 }
 
+// One scan + select + exact re-score + margin finish at list length KL.  fast: stage 1 of the two-stage search of an
+// fp32-exact index -- for the duration of the launch the index is viewed as the bf16 index rows_hi (pitch hp) with the
+// bf16 queries qhi; the re-score and the margin check still run on the fp32 rows (launch_search: fast_f32).  Queries the
+// widened margin cannot certify are re-scanned by finish_margin on the three-segment scan with K' = 32 lists.
+template <int KL>
+int scan_and_finish(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, bool packed, int64_t idx_offset, bool out_dev, hipStream_t st,
+                    hipStream_t tail_st, bool split, bool fast) {
+    int rc;
+    if (fast) {
+        uint8_t* rows_keep = ix->rows;
+        const int ld_keep = ix->ld, plane_keep = ix->plane;
+        ix->rows = ix->rows_hi;
+        ix->ld = ix->hp;
+        ix->plane = 0;
+        ix->plane_keep = plane_keep;
+        ix->fast_f32 = true;
+        std::swap(ix->qbuf, ix->qhi);
+        rc = launch_search<KL>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st, tail_st, split);
+        std::swap(ix->qbuf, ix->qhi);
+        ix->rows = rows_keep;
+        ix->ld = ld_keep;
+        ix->plane = plane_keep;
+        ix->fast_f32 = false;
+    } else {
+        rc = launch_search<KL>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st, tail_st, split);
+    }
+    if (rc) return rc;
+    if (split) {
+        ix->last_flagged = -1; // counted on the device only
+        return MIPS_OK;
+    }
+    rc = finish_margin<KL>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, fast);
+    // stage 1 pays while few queries need the second scan: after a call that sent more than a quarter there, skip it for a while
+    if (!rc && fast && ix->opt_f32_fast == 1 && ix->last_flagged >= 16 && ix->last_flagged * 4 > nq) ix->fast_skip = 8;
+    return rc;
+}
+
 } // namespace
 
 extern "C" {
@@ -973,6 +1069,8 @@ int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, 
     if (doc_dtype == MIPS_DTYPE_F32) {
         ix->plane = ix->ld;
         ix->ld = 2 * ix->plane;
+        // a pitch at which the query-stationary kernels have K' = 32 lists (256 / 512 / 768); 1024: K' <= 10 only
+        if (d <= 1024) ix->hp = d <= 256 ? 256 : d <= 512 ? 512 : d <= 768 ? 768 : 1024;
     }
     ix->doc_dtype = doc_dtype;
     ix->metric = metric;
@@ -1028,6 +1126,10 @@ int mips_index_destroy(mips_index_t* ix) {
     if (ix->nflag_host) (void)hipHostFree(ix->nflag_host);
     if (ix->tiny_words) (void)hipFree(ix->tiny_words);
     if (ix->rows_f32) (void)hipFree(ix->rows_f32);
+    if (ix->rows_hi) (void)hipFree(ix->rows_hi);
+    if (ix->dres2_dev) (void)hipFree(ix->dres2_dev);
+    ix->qhi.release();
+    ix->qerr2.release();
     for (int e = 0; e < mips_index::kEvRing; ++e) {
         if (ix->ev0[e]) (void)hipEventDestroy(ix->ev0[e]);
         if (ix->ev1[e]) (void)hipEventDestroy(ix->ev1[e]);
@@ -1075,15 +1177,18 @@ int mips_index_add(mips_index_t* ix, const void* rows, int64_t n, int src_dtype,
     ix->ntotal += n;
     if (!ix->phi_override) ix->phi_valid = false;
     ix->xmax2_valid = false;
+    ix->dres2_valid = false;
     return MIPS_OK;
 }
 
 int mips_index_reset(mips_index_t* ix) {
     if (!ix) return fail(MIPS_E_INVALID, "mips_index_reset: index is NULL");
     ix->ntotal = 0;
+    ix->hi_rows = 0;
     ix->phi_valid = false;
     ix->phi_override = false;
     ix->xmax2_valid = false;
+    ix->dres2_valid = false;
     return MIPS_OK;
 }
 
@@ -1159,6 +1264,7 @@ int mips_index_add_synthetic(mips_index_t* ix, int64_t n, int64_t row0, uint64_t
     ix->ntotal += n;
     if (!ix->phi_override) ix->phi_valid = false; // as mips_index_add: an override stays until the caller renews it
     ix->xmax2_valid = false;
+    ix->dres2_valid = false;
     return MIPS_OK;
 }
 
@@ -1304,14 +1410,37 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
         // sub-lists of 6, so MFMA ranks 1 .. 6 = k + 1 for certain and 7 .. 8 unless 6 better documents share the
         // sub-list (rows congruent mod 16 within a split).  Queries whose k-th exact score is too close to what the
         // pool may have lost are detected by the re-score and re-scanned with the widest lists (margin check below).
-        if (k <= 5) {
-            rc = launch_search<8>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st, tail_st, split);
-            if (!rc && !split) rc = finish_margin<8>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
-            if (!rc && split) ix->last_flagged = -1; // counted on the device only
+        // fp32-exact index: two-stage search when the call may synchronise anyway (see mips_index: rows_hi).  Stage 1 keeps
+        // K' = 32 lists where the bf16 kernels have them (pitch 256 / 512 / 768): the pool's bound is then the ~33rd best
+        // score, far enough below the k-th for the widened margin to certify nearly every query on well-separated data
+        // (with K' = 8 pools 44 % of the queries of a Gaussian test set went to the second stage; pitch 1024 has no more).
+        const bool hi_long = ix->hp == 256 || ix->hp == 512 || ix->hp == 768;
+        bool fast = ix->plane > 0 && ix->hp > 0 && (hi_long || k <= 7) && ix->opt_f32_fast != 0 && ix->opt_margin != 0 && !split &&
+                    (ix->opt_f32_fast == 2 || !out_dev || ix->opt_margin == 2);
+        if (fast && ix->opt_f32_fast == 1 && ix->fast_skip > 0) {
+            --ix->fast_skip;
+            fast = false;
+        }
+        if (fast) { // bf16(q) at the bf16 kernels' row pitch, |q - bf16 q|^2, bf16 rows and residual bound up to date
+            rc = ix->qhi.ensure((size_t)nq_pad * ix->hp * 2);
+            if (rc) return rc;
+            rc = ix->qerr2.ensure((size_t)nq * sizeof(double));
+            if (rc) return rc;
+            mips::convert_rows_kernel<float><<<grid_for(nq_pad * (int64_t)(ix->hp / 8), 256), 256, 0, st>>>((const float*)ix->qf32.p, nq, ix->plane,
+                                                                                                           (uint16_t*)ix->qhi.p, ix->hp, nq_pad);
+            mips::query_resid_kernel<<<(int)((nq + 3) / 4), 256, 0, st>>>((const float*)ix->qf32.p, nq, ix->plane, (double*)ix->qerr2.p);
+            HIP_TRY(hipGetLastError());
+            rc = ensure_hi(ix, st);
+            if (rc) return rc;
+            rc = ensure_xmax2(ix, st); // (on the fp32 rows: before the index is viewed as rows_hi)
+            if (rc) return rc;
+        }
+        if (fast && hi_long) {
+            rc = scan_and_finish<32>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, tail_st, split, true);
+        } else if (k <= 5) {
+            rc = scan_and_finish<8>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, tail_st, split, fast);
         } else if (k <= 7) { // k + 1 = 6 is what Mips.search fetches for top_k = 5 with ignore_indexes (mips.py:388-398)
-            rc = launch_search<10>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st, tail_st, split);
-            if (!rc && !split) rc = finish_margin<10>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
-            if (!rc && split) ix->last_flagged = -1; // counted on the device only
+            rc = scan_and_finish<10>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, tail_st, split, fast);
         } else if (k <= 13) {
             rc = launch_search<16>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st, tail_st, split);
             if (!rc && !split) rc = finish_margin<16>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
@@ -1523,7 +1652,11 @@ int mips_index_set_param(mips_index_t* ix, const char* name, int64_t value) {
     else if (n == "qgroups") ix->opt_qgroups = (int)value;
     else if (n == "variant") ix->opt_variant = (int)value;
     else if (n == "tiny") ix->opt_tiny = value == 2 ? 2 : value != 0 ? 1 : 0; // 2: one launch, fall-back paths forced (tests)
-    else if (n == "margin_check") {
+    else if (n == "f32_fast") {
+        if (value < 0 || value > 2) return fail(MIPS_E_INVALID, "mips_index_set_param: f32_fast must be 0, 1 or 2");
+        ix->opt_f32_fast = (int)value;
+        ix->fast_skip = 0;
+    } else if (n == "margin_check") {
         if (value < 0 || value > 2) return fail(MIPS_E_INVALID, "mips_index_set_param: margin_check must be 0, 1 or 2");
         ix->opt_margin = (int)value;
     } else if (n == "spin_limit") ix->opt_spin_limit = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 30));

@@ -253,7 +253,8 @@ class MipsIndex:
         return out
 
     def set_param(self, name: str, value: int) -> None:
-        """Launch tuning knob ("nsplit", "qgroups", "variant"); never changes results.  ("spin_limit" is the
+        """Launch tuning knob ("nsplit", "qgroups", "variant", "f32_fast": two-stage search of an fp32-exact index,
+        0 off / 1 when the call may synchronise / 2 always); never changes certified results.  ("spin_limit" is the
         test-only bound of the scan's block barrier, include/mips_hip.h.)"""
         _lib.check(self._lib.mips_index_set_param(self._h, name.encode(), int(value)), "mips_index_set_param")
 

@@ -886,6 +886,61 @@ def test_f32_exact_index_parity(tmp_path, n, nq, d, k, metric):
         assert back.dtype == "f32" and np.array_equal(i2, ei) and np.array_equal(s2, es)
 
 
+@pytest.mark.parametrize("n,nq,d,k,metric", [(60000, 700, 768, 5, 0), (20000, 40, 300, 6, 1), (9000, 300, 1000, 5, 0), (30000, 100, 500, 12, 0)])
+def test_f32_exact_two_stage_search(n, nq, d, k, metric):
+    """fp32-exact index, k <= 7, host buffers: stage 1 scans bf16(x) with the fast bf16 kernels and re-scores on the fp32
+    rows; the margin check -- widened by |x - bf16 x| |q| + |bf16 x| |q - bf16 q| -- sends what it cannot certify to the
+    three-segment scan.  Same bits as the oracle and as the one-stage search ("f32_fast" = 0); device-output searches
+    keep the one-stage scan unless "f32_fast" = 2."""
+    rng = np.random.default_rng(n + d)
+    x = (rng.standard_normal((n, d)) * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    es, ei = orc.search_exact(q, x, k, metric=metric)
+    ix = ram.MipsIndex(d, metric=metric, dtype="f32")
+    ix.add(x[:n // 3])
+    s, i = ix.search(q[:5], k)                                    # (bf16 rows are converted lazily: more rows follow)
+    ix.add(x[n // 3:])
+    s, i = ix.search(q, k)
+    assert not ix.last_kernel.startswith("mips::scan_kernel<"), ix.last_kernel   # a query-stationary bf16 kernel
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+    st = ix.margin_stats()
+    assert st["flagged"] >= 0 and st["rescanned"] == st["flagged"] and st["unresolved"] == 0
+    print("two-stage:", n, nq, d, k, metric, ix.last_kernel, st)
+    assert st["flagged"] < (nq // 2 if d > 768 else max(2, nq // 10))   # Gaussian rows: stage 1 certifies nearly all (K' = 32 pools)
+    qd = torch.from_numpy(q).cuda()
+    sd, idd = ix.search(qd, k)                                    # device outputs: one-stage (nothing may synchronise)
+    assert ix.last_kernel.startswith("mips::scan_kernel<")
+    assert np.array_equal(idd.cpu().numpy(), ei) and np.array_equal(sd.cpu().numpy(), es)
+    ix.set_param("f32_fast", 2)
+    sd, idd = ix.search(qd, k)
+    assert not ix.last_kernel.startswith("mips::scan_kernel<")
+    rows_ok = (idd.cpu().numpy() == ei).all(axis=1)
+    assert rows_ok.sum() >= nq - ix.margin_stats()["flagged"]     # every certified query is exact
+    ix.set_param("f32_fast", 0)
+    s0, i0 = ix.search(q, k)
+    assert ix.last_kernel.startswith("mips::scan_kernel<") and np.array_equal(i0, ei) and np.array_equal(s0, es)
+
+
+def test_f32_exact_two_stage_near_duplicates():
+    """Near-duplicate clusters: bf16(x) cannot separate the members, nearly every query goes to the second stage -- the
+    results must not care (and stage 1 is skipped for the next calls)."""
+    rng = np.random.default_rng(5)
+    c = rng.standard_normal((300, 768)).astype(np.float32)
+    x = (np.repeat(c, 40, axis=0) * (1.0 + 1e-4 * rng.standard_normal((12000, 1)))).astype(np.float32)
+    x += (1e-4 * rng.standard_normal(x.shape)).astype(np.float32)
+    q = (c[rng.integers(0, 300, 64)] + 0.01 * rng.standard_normal((64, 768))).astype(np.float32)
+    es, ei = orc.search_exact(q, x, 5)
+    ix = ram.MipsIndex(768, dtype="f32")
+    ix.add(x)
+    for rep in range(3):
+        s, i = ix.search(q, 5)
+        assert np.array_equal(i, ei) and np.array_equal(s, es), rep
+        if rep == 0:
+            assert ix.margin_stats()["flagged"] > 16 and not ix.last_kernel.startswith("mips::scan_kernel<")
+        else:
+            assert ix.last_kernel.startswith("mips::scan_kernel<")   # stage 1 skipped after the call that did not pay
+
+
 def test_f32_exact_synthetic_and_ties():
     ix = ram.MipsIndex(768, dtype="f32")
     ix.add_synthetic(3000, row0=10, seed=5, kind=synth.KIND_LATTICE)
