@@ -246,6 +246,10 @@ int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out
  * mips_index_margin_stats.  "f32_fast" (fp32-exact index): 0 = always the three-segment scan, 1 (default) = two-stage search
  * when the call may synchronise, skipped for 8 calls after one that sent more than a quarter of its queries to the second
  * stage, 2 = two-stage always (device-output searches then only COUNT the uncertified queries, like every margin check).
+ * The same switch (alias "optimistic") governs bf16 searches with 8 <= k <= 13 that certify (host buffers or "margin_check" = 2)
+ * at row pitches 384 .. 768: their pool of 32 candidates is then selected from the 16x16x32 kernel's sub-lists (the fast
+ * kernel) instead of from true K' = 16 lists; the margin check decides per query whether that pool was wide enough and the
+ * others are re-scanned with K' = 32 lists.
  * Two more names exist for tests and experiments and are NOT tuning knobs:
  *   "spin_limit"  polls a wave spends on the scan's block barrier before it gives up (0 = the shipped 2^22).  A tiny
  *                 value makes the kernel give up spuriously and -1 makes every scan launch raise its error word

@@ -118,6 +118,11 @@ struct mips_index {
     bool dres2_valid = false;
     int opt_f32_fast = 1;        // 0 off, 1 when the call may synchronise (host buffers / margin_check = 2), 2 always
     bool fast_f32 = false;       // launch_search: stage 1 in progress (index viewed as bf16 rows_hi)
+    // "Optimistic" scan (calls that certify, i.e. may synchronise): pools of 16 / 32 candidates selected from the 16x16x32
+    // kernel's 4 sub-lists of 6 instead of from true K'-entry lists on the 4-wave configuration.  What the pool may have
+    // excluded is bounded all the same (merge_select: sub-lists' last entries), so the margin check decides per query;
+    // flagged queries are re-scanned with true K' = 32 lists.
+    bool optimistic = false;
     int plane_keep = 0;
     int fast_skip = 0;           // calls left to skip stage 1 for (the last one flagged too many queries to pay)
     bool phi_valid = false;
@@ -416,7 +421,9 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // there when more than one query tile shares the document stream (the MFMA-bound regime, where the shape's
     // higher clock pays: 4.54 vs 4.78 ms at BASELINE config 2); single-tile searches are HBM-bound and keep
     // scan_kernel_v3's non-temporal document DMA.  "variant" = 3 / 4 forces one of the two.
-    const bool v4_shape = ix->ld % 128 == 0 && ix->ld >= 384 && ix->ld <= 768 && KL == 8 && ix->esize == 2 && ix->plane == 0;
+    const bool v4_opt = ix->optimistic && ix->rescan_depth == 0 && (KL == 16 || KL == 32) && ix->opt_variant == 0 && ix->opt_sub == 0 &&
+                        ix->ld % 128 == 0 && ix->ld >= 384 && ix->ld <= 768 && ix->esize == 2 && ix->plane == 0;
+    const bool v4_shape = ix->ld % 128 == 0 && ix->ld >= 384 && ix->ld <= 768 && (KL == 8 || v4_opt) && ix->esize == 2 && ix->plane == 0;
     // scan_kernel_v5 (64 stationary queries per wave, one wave per SIMD): row pitches whose 64-k slabs divide evenly
     // among 4 waves
     const bool v5_shape = (ix->ld == 768 || ix->ld == 512) && KL == 8 && ix->esize == 2 && ix->plane == 0;
@@ -432,13 +439,13 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     if (f8) {
         if (ix->ld % 256 != 0 || ix->ld > 1024 || KL > 16) return fail(MIPS_E_UNSUPPORTED, "fp8 index: d must pad to 256/512/768/1024 and k <= 13");
         variant = 3;
-    } else if (f32x || !v3_dim || (!kl_short && !v3_long)) {
+    } else if (f32x || !v3_dim || (!kl_short && !v3_long && !v4_opt)) {
         variant = 1; // no query-stationary configuration: generic tiles
     }
     // K' = 8 / 10 (k <= 7) at d <= 768: 8 waves, two per SIMD (256 registers each, no spill up to K' = 10).
     // Longer lists or d = 1024 do not fit next to the fragments there: 4 waves, one per SIMD, 512 registers,
     // 128 queries per workgroup.
-    const int v3_waves = (!f8 && (ix->ld == 1024 || !kl_short)) ? 4 : 8;
+    const int v3_waves = (!f8 && !v4_opt && (ix->ld == 1024 || !kl_short)) ? 4 : 8;
     // fp8: scan_kernel_f8x (16x16x128 MFMA shape, 64-document blocks, 4 sub-lists of 6) for k <= 5 and row pitches
     // up to 768 bytes; scan_kernel_f8 (32x32x64, 32-document blocks) otherwise or when "variant" = 3 asks for it
     const bool want_f8x = f8 && KL == 8 && ix->ld <= 768 && ix->opt_variant != 3;
@@ -451,7 +458,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // regime on large indexes (3.80 vs 3.82 ms at Q = 64 on 2^24 rows), loses 3-8 % on short streams at Q = 8 (0.315 vs
     // 0.304 ms at 2^20 rows, 0.091 vs 0.084 at 2^17) and wins once several waves multiply (3.89 vs 4.15 ms at Q = 128,
     // 5.57 vs 5.98 at Q = 256; profiles/r2_final/ab_single_tile.md): scan_kernel_v3 up to 64 queries, v4 beyond
-    const bool want_v4 = !want_v5 && (v4_forced || (v4_auto && (nqt > 1 || nq > 64)));
+    const bool want_v4 = !want_v5 && (v4_forced || v4_opt || (v4_auto && (nqt > 1 || nq > 64)));
     // scan_kernel_ks (K split over a wave pair, two waves per SIMD): row pitch 1024, k <= 5.  Selectable ("variant" =
     // 6), not the default: measured 30.6 vs 31.3 ms at 2^22 x 1024 against the one-wave-per-SIMD scan_kernel_v3
     // configuration (profiles/r2_pitch1024) -- both sit on the L2 -> LDS fill of 128 stationary queries per CU
@@ -567,7 +574,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             set_kernel_name(ix, "mips::scan_kernel_v5<%d, %d, 2, 0>", V4_KLL, ix->ld / 32);
         }
     } else if (want_v4) {
-        if constexpr (KL == 8) {
+        if constexpr (KL == 8 || KL == 16 || KL == 32) {
             const int lds = 3 * mips::V3_DB * ix->ld * 2 + 8 * 1024 + 1024 + 16; // ring + threshold words + dump area + arrival counter
             auto go4 = [&](auto kern) -> int {
                 HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -581,12 +588,19 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             if (ix->ld == 768 && ix->opt_sub == 8) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 1>); // timing only: no epilogue
             else
 #endif
+            if (v4_opt) { // pools of 16 / 32: every sub-list vouches for its 4th best (8 x 4 = 32 documents above the bound)
+                if (ix->ld == 768) rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 0, true, 4>) : go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 0, false, 4>);
+                else if (ix->ld == 640) rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 20, 2, 0, true, 4>) : go4(mips::scan_kernel_v4<V4_KLL, 20, 2, 0, false, 4>);
+                else if (ix->ld == 512) rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 16, 2, 0, true, 4>) : go4(mips::scan_kernel_v4<V4_KLL, 16, 2, 0, false, 4>);
+                else rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 12, 2, 0, true, 4>) : go4(mips::scan_kernel_v4<V4_KLL, 12, 2, 0, false, 4>);
+            } else
             if (ix->ld == 768) rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 0, true>) : go4(mips::scan_kernel_v4<V4_KLL, 24, 2>);
             else if (ix->ld == 640) rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 20, 2, 0, true>) : go4(mips::scan_kernel_v4<V4_KLL, 20, 2>);
             else if (ix->ld == 512) rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 16, 2, 0, true>) : go4(mips::scan_kernel_v4<V4_KLL, 16, 2>);
             else rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 12, 2, 0, true>) : go4(mips::scan_kernel_v4<V4_KLL, 12, 2>);
             if (rc2) return rc2;
-            set_kernel_name(ix, nt ? "mips::scan_kernel_v4<%d, %d, 2, 0, true>" : "mips::scan_kernel_v4<%d, %d, 2, 0, false>", V4_KLL, ix->ld / 32);
+            set_kernel_name(ix, nt ? "mips::scan_kernel_v4<%d, %d, 2, 0, true, %d>" : "mips::scan_kernel_v4<%d, %d, 2, 0, false, %d>", V4_KLL, ix->ld / 32,
+                            v4_opt ? 4 : 1);
         }
     } else if (want_f8x) {
         if constexpr (KL == 8) {
@@ -1001,8 +1015,9 @@ int finish_margin(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, b
 // widened margin cannot certify are re-scanned by finish_margin on the three-segment scan with K' = 32 lists.
 template <int KL>
 int scan_and_finish(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, bool packed, int64_t idx_offset, bool out_dev, hipStream_t st,
-                    hipStream_t tail_st, bool split, bool fast) {
+                    hipStream_t tail_st, bool split, bool fast, bool optimistic = false) {
     int rc;
+    ix->optimistic = fast || optimistic;
     if (fast) {
         uint8_t* rows_keep = ix->rows;
         const int ld_keep = ix->ld, plane_keep = ix->plane;
@@ -1021,14 +1036,17 @@ int scan_and_finish(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
     } else {
         rc = launch_search<KL>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st, tail_st, split);
     }
+    const bool first_was_optimistic = ix->optimistic;
+    ix->optimistic = false;
     if (rc) return rc;
     if (split) {
         ix->last_flagged = -1; // counted on the device only
         return MIPS_OK;
     }
-    rc = finish_margin<KL>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, fast);
-    // stage 1 pays while few queries need the second scan: after a call that sent more than a quarter there, skip it for a while
-    if (!rc && fast && ix->opt_f32_fast == 1 && ix->last_flagged >= 16 && ix->last_flagged * 4 > nq) ix->fast_skip = 8;
+    rc = finish_margin<KL>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, first_was_optimistic);
+    // the optimistic scan pays while few queries need the second one: after a call that sent more than a quarter there, skip
+    // it for a while
+    if (!rc && first_was_optimistic && ix->opt_f32_fast != 2 && ix->last_flagged >= 16 && ix->last_flagged * 4 > nq) ix->fast_skip = 8;
     return rc;
 }
 
@@ -1069,8 +1087,9 @@ int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, 
     if (doc_dtype == MIPS_DTYPE_F32) {
         ix->plane = ix->ld;
         ix->ld = 2 * ix->plane;
-        // a pitch at which the query-stationary kernels have K' = 32 lists (256 / 512 / 768); 1024: K' <= 10 only
-        if (d <= 1024) ix->hp = d <= 256 ? 256 : d <= 512 ? 512 : d <= 768 ? 768 : 1024;
+        // a pitch at which the query-stationary kernels serve pools of 32: 256 (true K' = 32 lists), 384 .. 768 (16x16x32
+        // kernel, optimistic pools); 1024: K' <= 10 only
+        if (d <= 1024) ix->hp = d <= 256 ? 256 : d <= 768 ? (int)round_up(d, 128) : 1024;
     }
     ix->doc_dtype = doc_dtype;
     ix->metric = metric;
@@ -1414,7 +1433,7 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
         // K' = 32 lists where the bf16 kernels have them (pitch 256 / 512 / 768): the pool's bound is then the ~33rd best
         // score, far enough below the k-th for the widened margin to certify nearly every query on well-separated data
         // (with K' = 8 pools 44 % of the queries of a Gaussian test set went to the second stage; pitch 1024 has no more).
-        const bool hi_long = ix->hp == 256 || ix->hp == 512 || ix->hp == 768;
+        const bool hi_long = ix->hp > 0 && ix->hp <= 768;
         bool fast = ix->plane > 0 && ix->hp > 0 && (hi_long || k <= 7) && ix->opt_f32_fast != 0 && ix->opt_margin != 0 && !split &&
                     (ix->opt_f32_fast == 2 || !out_dev || ix->opt_margin == 2);
         if (fast && ix->opt_f32_fast == 1 && ix->fast_skip > 0) {
@@ -1442,9 +1461,15 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
         } else if (k <= 7) { // k + 1 = 6 is what Mips.search fetches for top_k = 5 with ignore_indexes (mips.py:388-398)
             rc = scan_and_finish<10>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, tail_st, split, fast);
         } else if (k <= 13) {
-            rc = launch_search<16>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st, tail_st, split);
-            if (!rc && !split) rc = finish_margin<16>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
-            if (!rc && split) ix->last_flagged = -1; // counted on the device only
+            // bf16 index, a call that certifies: pool of 32 out of the 16x16x32 kernel's sub-lists (see mips_index::optimistic)
+            bool opt = ix->plane == 0 && ix->esize == 2 && ix->opt_margin != 0 && !split && (!out_dev || ix->opt_margin == 2) &&
+                       ix->opt_f32_fast != 0 && ix->ld % 128 == 0 && ix->ld >= 384 && ix->ld <= 768;
+            if (opt && ix->fast_skip > 0) {
+                --ix->fast_skip;
+                opt = false;
+            }
+            if (opt) rc = scan_and_finish<32>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, tail_st, split, false, true);
+            else rc = scan_and_finish<16>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, tail_st, split, false);
         } else {
             rc = launch_search<32>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st, tail_st, split);
             if (!rc && !split) rc = finish_margin<32>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
@@ -1652,8 +1677,8 @@ int mips_index_set_param(mips_index_t* ix, const char* name, int64_t value) {
     else if (n == "qgroups") ix->opt_qgroups = (int)value;
     else if (n == "variant") ix->opt_variant = (int)value;
     else if (n == "tiny") ix->opt_tiny = value == 2 ? 2 : value != 0 ? 1 : 0; // 2: one launch, fall-back paths forced (tests)
-    else if (n == "f32_fast") {
-        if (value < 0 || value > 2) return fail(MIPS_E_INVALID, "mips_index_set_param: f32_fast must be 0, 1 or 2");
+    else if (n == "f32_fast" || n == "optimistic") { // (one switch: two-stage fp32 search and optimistic pools, include/mips_hip.h)
+        if (value < 0 || value > 2) return fail(MIPS_E_INVALID, "mips_index_set_param: f32_fast / optimistic must be 0, 1 or 2");
         ix->opt_f32_fast = (int)value;
         ix->fast_skip = 0;
     } else if (n == "margin_check") {

@@ -16,8 +16,11 @@
 //     document of global rank r can only be pushed out of its sub-list by KL better documents of the same
 //     sub-list, so ranks 1 .. KL survive for certain (KL = 6 = k + 1 for k <= 5), the re-score pool is the
 //     8 best of the union;
-//   * shared insert bounds as scan_kernel_v3 TMODE 2: every sub-list publishes its best score into class word
-//     (4 split + g) & 7 of its query, the bound is the minimum of the 8 words, re-read sparsely.
+//   * shared insert bounds as scan_kernel_v3 TMODE 2: every sub-list publishes its best score (PUB = 1; its PUB-th best
+//     in general) into class word (4 split + g) & 7 of its query, the bound is the minimum of the 8 words, re-read
+//     sparsely: 8 PUB distinct documents score at least the bound, so nothing below it belongs to a pool of 8 PUB.
+//     PUB = 4 serves the "optimistic" pools of 32 (mips_hip.hip): the lists still keep 6 entries each, the margin
+//     check decides per query whether the pool selected from them was wide enough.
 // Everything else (LDS-DMA ring, counted vmcnt, split barrier, strict-'>' tie rule) is scan_kernel_v3's.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -41,7 +44,7 @@ __device__ __forceinline__ unsigned lane_id_here() {
 }
 
 // NT_DOCS: non-temporal document DMA -- for searches of ONE query tile, where every document block has a single reader
-template <int KL, int KS32, int AD, int TIMING_MODE = 0, bool NT_DOCS = false>
+template <int KL, int KS32, int AD, int TIMING_MODE = 0, bool NT_DOCS = false, int PUB = 1>
 __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WAVES = 8;
@@ -52,6 +55,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
     constexpr int PPW = PIECES / WAVES;
     static_assert(PIECES % WAVES == 0, "every wave must issue the same number of DMA pieces");
     static_assert(KL <= 8, "8 class words vouch for 8 documents");
+    static_assert(PUB >= 1 && PUB <= KL, "a sub-list publishes one of its entries");
     constexpr int STEPS = 2 * KS32; // k32-steps per block (two halves)
 
     const int tid = threadIdx.x;
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
             const int base = blk * V3_DB + 16 * half + (int)((thr_addr >> 6) & 12u); // + 4 g, from the lane bits
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const float mark = ls[n][0];
+                const float mark = ls[n][PUB - 1];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float s = acc[n][r];
@@ -196,9 +200,9 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
                         thr[n] = fmaxf(thr[n], ls[n][KL - 1]);
                     }
                 }
-                if (ls[n][0] > mark) { // new best of this sub-list: raise its class word, (4 split + g) & 7
+                if (ls[n][PUB - 1] > mark) { // new PUB-th best of this sub-list: raise its class word, (4 split + g) & 7
                     const unsigned cls = (4u * (unsigned)split + ((thr_addr >> 8) & 3u)) & 7u;
-                    publish_umax(thr_encode(ls[n][0]), (thr_addr & ~0x3FFu) + ((thr_addr & 0xF0u) << 1) + 512u * n + 4u * cls, thr_rsrc);
+                    publish_umax(thr_encode(ls[n][PUB - 1]), (thr_addr & ~0x3FFu) + ((thr_addr & 0xF0u) << 1) + 512u * n + 4u * cls, thr_rsrc);
                 }
             }
         }

@@ -921,6 +921,60 @@ def test_f32_exact_two_stage_search(n, nq, d, k, metric):
     assert ix.last_kernel.startswith("mips::scan_kernel<") and np.array_equal(i0, ei) and np.array_equal(s0, es)
 
 
+@pytest.mark.parametrize("n,nq,d,k", [(50000, 600, 768, 10), (30000, 70, 500, 13), (20000, 300, 384, 8)])
+def test_optimistic_pools_for_k_8_to_13(n, nq, d, k):
+    """bf16 index, 8 <= k <= 13, host buffers (a call that certifies): the pool of 32 comes out of the 16x16x32 kernel's
+    sub-lists of 6 and the margin check decides per query; flagged queries are re-scanned with true K' = 32 lists.  Same
+    bits as the oracle and as the K' = 16 lists ("optimistic" = 0 / device outputs)."""
+    x = synth.generate(401, 0, n, d, synth.KIND_GAUSS)
+    q = synth.generate(402, 0, nq, d, synth.KIND_GAUSS)
+    es, ei = orc.search_exact(q, x, k)
+    ix = _index(x)
+    s, i = ix.search(q, k)
+    assert ix.last_kernel.startswith("mips::scan_kernel_v4"), ix.last_kernel
+    st = ix.margin_stats()
+    print("optimistic:", n, nq, d, k, ix.last_kernel, st)
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+    assert st["unresolved"] == 0 and st["rescanned"] == st["flagged"]
+    sd, idd = ix.search(torch.from_numpy(q).cuda(), k)           # device outputs: true K' = 16 lists
+    assert not ix.last_kernel.startswith("mips::scan_kernel_v4")
+    assert np.array_equal(idd.cpu().numpy(), ei) and np.array_equal(sd.cpu().numpy(), es)
+    ix.set_param("optimistic", 0)
+    s0, i0 = ix.search(q, k)
+    assert not ix.last_kernel.startswith("mips::scan_kernel_v4") and np.array_equal(i0, ei) and np.array_equal(s0, es)
+    # crowd one sub-list: rows congruent mod 16 inside one split, all near the top of query 0 -> that query must be flagged or exact
+    y = x.copy()
+    for j in range(12):
+        y[160 + 16 * j] = q[0] * np.float32(1.0 + 0.01 * j)
+    y = synth.round_to_bf16(y)
+    ix2 = _index(y)
+    es2, ei2 = orc.search_exact(q, y, k)
+    s2, i2 = ix2.search(q, k)
+    assert np.array_equal(i2, ei2) and np.array_equal(s2, es2)
+
+
+def test_optimistic_pools_agree_with_true_lists_at_full_size():
+    """BASELINE config 2's index (2^20 x 768), k = 10: optimistic pools of 32 out of the 16x16x32 kernel's sub-lists (each
+    sub-list vouching for its 4th best: 8 classes x 4 = 32 documents above the shared insert bound) against true K' = 16 and
+    K' = 32 lists.  With the 8-document bound of the k <= 5 instances two of these 4096 queries lost their 10th neighbour
+    uncertified -- this size is what showed it."""
+    ix = ram.MipsIndex(768)
+    ix.add_synthetic(1 << 20, 0, synth.SEED_DOCS, synth.KIND_GAUSS)
+    q = ram.synth_fill(4096, 768, 0, synth.SEED_QUERIES, synth.KIND_GAUSS)
+    ix.set_param("margin_check", 2)
+    ix.set_param("optimistic", 0)
+    s0, i0 = ix.search(q, 10)
+    assert ix.last_kernel.startswith("mips::scan_kernel_v3<16")
+    ix.set_param("optimistic", 1)
+    s1, i1 = ix.search(q, 10)
+    assert ix.last_kernel.startswith("mips::scan_kernel_v4") and ix.last_kernel.endswith(", 4>")
+    assert ix.margin_stats()["unresolved"] == 0
+    s2, i2 = ix.search(q, 14)
+    assert ix.last_kernel.startswith("mips::scan_kernel_v3<32")
+    assert torch.equal(i0, i1) and torch.equal(s0, s1)
+    assert torch.equal(i0, i2[:, :10]) and torch.equal(s0, s2[:, :10])
+
+
 def test_f32_exact_two_stage_near_duplicates():
     """Near-duplicate clusters: bf16(x) cannot separate the members, nearly every query goes to the second stage -- the
     results must not care (and stage 1 is skipped for the next calls)."""
