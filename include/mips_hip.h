@@ -281,6 +281,11 @@ int mips_index_check_error(mips_index_t* index, int synchronize, void* hip_strea
  *   2  certify: mips_search synchronises and re-scans the flagged queries with the widest lists (K' = 32; 16 on an
  *      fp8 index), overwriting their rows.  Searches into HOST buffers synchronise anyway and always do this unless
  *      the check is off.
+ *   3  certify WITHOUT synchronising (device outputs): the flag list is compacted on the device and the re-scan is
+ *      enqueued behind the first scan, sized for all queries; its workgroups read the flagged count and leave when they are
+ *      past it.  Costs a handful of empty launches (tens of microseconds) when nothing is flagged.  Searches in this mode
+ *      also take the optimistic / two-stage paths ("f32_fast") and never the one-launch kernel; split-tail searches
+ *      (mips_search_split) only count.  Host-buffer searches behave as in mode 2.
  * Outputs of the LAST search on the index: flagged = queries flagged by the first pass (-1: only counted on the
  * device and synchronize == 0), rescanned = queries re-scanned, unresolved = queries still flagged afterwards (their
  * results are the best this build can do; on tie-free data they are exact in practice -- the MFMA error observed is
@@ -290,7 +295,7 @@ int mips_index_margin_stats(mips_index_t* index, int64_t* flagged, int64_t* resc
                             int synchronize, void* hip_stream);
 
 /* Name of the scan-kernel instance the last mips_search on this index dispatched to, in the form rocprofv3 prints
- * it (e.g. "mips::scan_kernel_v4<6, 24, 2, 0>"); "" before the first search.  bench.py's roofline.kernel. */
+ * it (e.g. "mips::scan_kernel_v4<6, 24, 2, 0, false, 1>"); "" before the first search.  bench.py's roofline.kernel. */
 const char* mips_index_last_kernel(const mips_index_t* index);
 
 /* Timing hook used by bench.py.  reset != 0 opens a measurement window: from then on every

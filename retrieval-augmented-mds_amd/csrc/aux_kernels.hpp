@@ -413,6 +413,7 @@ struct MergeArgs {
     // from that by at most |x - bf16 x| |q| + |bf16 x| |q - bf16 q|  (Cauchy-Schwarz), added to the margin
     const double* dres2 = nullptr; // device scalar: max_i |x_i - bf16(x_i)|^2 over the stored rows
     const double* qerr2 = nullptr; // [nq]: |q - bf16(q)|^2
+    const int* nq_dev = nullptr;   // stream-ordered re-scan: the query count lives on the device (launches sized for the maximum)
 };
 
 // What a search whose scan kernel gave up (split-barrier spin bound, scan_kernel_v3.hpp) returns instead of
@@ -524,6 +525,7 @@ __device__ __forceinline__ void merge_select_body(const MergeArgs& p, int* cand,
 
 template <int KL>
 __global__ __launch_bounds__(64) void merge_select_kernel(MergeArgs p, int* cand) {
+    if (p.nq_dev != nullptr && (int)blockIdx.x >= *p.nq_dev) return;
     merge_select_body<KL>(p, cand, (int)blockIdx.x, (int)threadIdx.x);
 }
 
@@ -672,6 +674,7 @@ __device__ __forceinline__ void rescore_rank_body(const MergeArgs& p, const int*
 
 template <int KL, typename EL, bool L2>
 __global__ __launch_bounds__(64) void rescore_rank_kernel(MergeArgs p, const int* cand, int64_t nq) {
+    if (p.nq_dev != nullptr) nq = *p.nq_dev;
     rescore_rank_body<KL, EL, L2>(p, cand, nq, (int64_t)blockIdx.x, (int)threadIdx.x);
 }
 
@@ -858,7 +861,10 @@ __global__ __launch_bounds__(256) void cosine_rescore_bwd_kernel(const T* query,
 
 // ------------------------------------------------------------------ re-scan of flagged queries: gather / scatter
 // gather staged query rows (row_bytes each, a multiple of 16) ids[t] -> row t; rows n .. n_out - 1 are zeroed
-__global__ void gather_rows_kernel(const unsigned char* src, const int* ids, int64_t n, int64_t n_out, int row_bytes, unsigned char* dst) {
+// n_dev (optional): the row count lives on the device (stream-ordered re-scan); n is then ignored
+__global__ void gather_rows_kernel(const unsigned char* src, const int* ids, int64_t n, int64_t n_out, int row_bytes, unsigned char* dst,
+                                   const int* n_dev = nullptr) {
+    if (n_dev != nullptr) n = *n_dev;
     const int chunks = row_bytes / 16;
     const int64_t total = n_out * chunks;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -871,15 +877,39 @@ __global__ void gather_rows_kernel(const unsigned char* src, const int* ids, int
 }
 // scatter result rows back: row t of the compact results -> row ids[t]; `words` 8-byte words per row (k for the
 // index array or the packed payload's 2 k; the float scores go through scatter_f32)
-__global__ void scatter_i64_kernel(const int64_t* src, const int* ids, int64_t n, int words, int64_t* dst) {
+__global__ void scatter_i64_kernel(const int64_t* src, const int* ids, int64_t n, int words, int64_t* dst, const int* n_dev = nullptr) {
+    if (n_dev != nullptr) n = *n_dev;
     const int64_t total = n * words;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
         dst[(size_t)ids[t / words] * words + t % words] = src[t];
 }
-__global__ void scatter_f32_kernel(const float* src, const int* ids, int64_t n, int words, float* dst) {
+__global__ void scatter_f32_kernel(const float* src, const int* ids, int64_t n, int words, float* dst, const int* n_dev = nullptr) {
+    if (n_dev != nullptr) n = *n_dev;
     const int64_t total = n * words;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
         dst[(size_t)ids[t / words] * words + t % words] = src[t];
+}
+
+// flagged queries -> ascending list of their numbers + count (one workgroup; stream-ordered re-scan)
+__global__ __launch_bounds__(256) void compact_flags_kernel(const unsigned char* flags, int nq, int* ids, int* count) {
+    __shared__ int part[256];
+    const int t = threadIdx.x;
+    const int per = (nq + 255) / 256;
+    const int lo = t * per, hi = lo + per < nq ? lo + per : nq;
+    int c = 0;
+    for (int q = lo; q < hi; ++q) c += flags[q] ? 1 : 0;
+    part[t] = c;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) { // inclusive scan
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int w = part[t] - c;
+    for (int q = lo; q < hi; ++q)
+        if (flags[q]) ids[w++] = q;
+    if (t == 255) *count = part[255];
 }
 
 __global__ void fill_empty_kernel(float* out_s, int64_t* out_i, int64_t* out_packed, int64_t total, int metric) {

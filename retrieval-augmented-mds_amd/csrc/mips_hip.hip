@@ -123,6 +123,10 @@ struct mips_index {
     // excluded is bounded all the same (merge_select: sub-lists' last entries), so the margin check decides per query;
     // flagged queries are re-scanned with true K' = 32 lists.
     bool optimistic = false;
+    // "margin_check" = 3: device-output searches re-scan the queries they flag WITHOUT a synchronisation -- the flag list is
+    // compacted on the device and the second scan, sized for all queries, lets the workgroups past the count leave
+    const int* nq_dev = nullptr;         // launch_search: device-side query count of the re-scan in progress
+    const int* first_nflag_dev = nullptr; // flagged count of the first scan of the last mode-3 search (margin stats)
     int plane_keep = 0;
     int fast_skip = 0;           // calls left to skip stage 1 for (the last one flagged too many queries to pay)
     bool phi_valid = false;
@@ -524,6 +528,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     a.nsplit = nsplit;
     a.nqt = nqt;
     a.nq = (int)nq;
+    a.nq_dev = ix->nq_dev;
     a.qgroups = qgroups;
     a.qt_per_group = qt_per_group;
     a.splits_per_group = nsplit / (8 / qgroups);
@@ -751,6 +756,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // sum |q_j x_j| <= d 2^-23 |q| |x| (u = 2^-23 allows truncating adders).  fp32-exact mode scans hi.qhi + hi.qlo +
     // lo.qhi of bf16 splits: the dropped lo.qlo term adds 2^-16 |q| |x|, and there are three times the terms.
     m.err_c = f32x ? (3.0 * (double)ix->d * 1.1920928955078125e-07 + 1.52587890625e-05) : (double)ix->d * 1.1920928955078125e-07;
+    m.nq_dev = ix->nq_dev;
     if (ix->fast_f32) { // the scan's operands are bf16(q), bf16(x): norms within 2^-8 of |q|, |x|
         m.err_c *= 1.01;
         m.dres2 = ix->dres2_dev;
@@ -918,6 +924,74 @@ int tiny_search(mips_index* ix, const void* q_dev, int q_dtype, int64_t nq, int 
     return MIPS_OK;
 }
 
+// "margin_check" = 3, device outputs: the re-scan of finish_margin without its two synchronisations.  The flags of the first
+// scan are compacted into a list + count ON THE DEVICE; the staged rows of the flagged queries are gathered; the second scan
+// (widest lists) is launched for ALL nq queries' worth of workgroups, which read the count and leave when they are past it
+// (ScanArgs::nq_dev); select, re-score and the scatter over the first results do the same.  With nothing flagged this costs
+// a handful of empty launches (tens of microseconds); mips_index_margin_stats reads both counters when asked.
+template <int KL>
+int rescan_on_stream(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, bool packed, int64_t idx_offset, hipStream_t st, bool fast_first) {
+    const bool f8 = ix->esize == 1;
+    const int wide = f8 ? (KL < 16 ? 16 : 0) : (KL < 32 || fast_first ? 32 : 0);
+    ix->last_flagged = -1; // (device only)
+    if (wide == 0) return MIPS_OK; // already on the widest lists: counted only
+    const int64_t n_pad = round_up(nq, kQueryAlign);
+    const size_t row_bytes = (size_t)ix->ld * ix->esize;
+    int rc = ix->ids.ensure((size_t)(nq + 4) * sizeof(int));
+    if (rc) return rc;
+    int* ids = (int*)ix->ids.p;
+    int* cnt = ids + nq;
+    rc = ix->qbuf2.ensure((size_t)n_pad * row_bytes);
+    if (rc) return rc;
+    rc = ix->tmp_s.ensure((size_t)nq * k * sizeof(float));
+    if (rc) return rc;
+    rc = ix->tmp_i.ensure((size_t)nq * k * sizeof(int64_t) * 2);
+    if (rc) return rc;
+    mips::compact_flags_kernel<<<1, 256, 0, st>>>((const unsigned char*)ix->mflag.p, (int)nq, ids, cnt);
+    mips::gather_rows_kernel<<<grid_for(n_pad * (int64_t)(row_bytes / 16), 256), 256, 0, st>>>((const unsigned char*)ix->qbuf.p, ids, 0, n_pad, (int)row_bytes,
+                                                                                              (unsigned char*)ix->qbuf2.p, cnt);
+    if (ix->plane > 0) {
+        const size_t rb32 = (size_t)ix->plane * sizeof(float);
+        rc = ix->qf32b.ensure((size_t)n_pad * rb32);
+        if (rc) return rc;
+        mips::gather_rows_kernel<<<grid_for(n_pad * (int64_t)(rb32 / 16), 256), 256, 0, st>>>((const unsigned char*)ix->qf32.p, ids, 0, n_pad, (int)rb32,
+                                                                                            (unsigned char*)ix->qf32b.p, cnt);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(ix->gthr.p, 0, (size_t)(n_pad * 8 + 4) * sizeof(unsigned), st)); // insert bounds, error word, flag counter
+    std::swap(ix->qbuf, ix->qbuf2);
+    std::swap(ix->qf32, ix->qf32b);
+    const bool armed = ix->timing_armed;
+    char name_keep[sizeof ix->last_kernel];
+    std::memcpy(name_keep, ix->last_kernel, sizeof name_keep);
+    ix->timing_armed = false;
+    ix->rescan_depth = 1;
+    ix->nq_dev = cnt;
+    const int ns_keep = ix->opt_nsplit;
+    if (ns_keep == 0 && nq <= 8192) ix->opt_nsplit = 64; // the flagged queries are few: spread each of their tiles over many CUs
+    float* ts = (float*)ix->tmp_s.p;
+    int64_t* ti = (int64_t*)ix->tmp_i.p;
+    if (wide == 32) rc = launch_search<32>(ix, nq, k, ts, ti, packed ? ti : nullptr, idx_offset, st, nullptr, false);
+    else rc = launch_search<16>(ix, nq, k, ts, ti, packed ? ti : nullptr, idx_offset, st, nullptr, false);
+    ix->opt_nsplit = ns_keep;
+    ix->nq_dev = nullptr;
+    ix->rescan_depth = 0;
+    ix->timing_armed = armed;
+    std::memcpy(ix->last_kernel, name_keep, sizeof name_keep);
+    std::swap(ix->qbuf, ix->qbuf2);
+    std::swap(ix->qf32, ix->qf32b);
+    if (rc) return rc;
+    if (packed) {
+        mips::scatter_i64_kernel<<<grid_for(nq * 2 * k, 256), 256, 0, st>>>(ti, ids, 0, 2 * k, d_i, cnt);
+    } else {
+        mips::scatter_i64_kernel<<<grid_for(nq * k, 256), 256, 0, st>>>(ti, ids, 0, k, d_i, cnt);
+        mips::scatter_f32_kernel<<<grid_for(nq * k, 256), 256, 0, st>>>(ts, ids, 0, k, d_s, cnt);
+    }
+    HIP_TRY(hipGetLastError());
+    ix->first_nflag_dev = (const int*)cnt; // last_nflag_dev: the re-scan's own counter (still flagged on the widest lists)
+    return MIPS_OK;
+}
+
 // Margin check, host side.  The re-score flagged every query whose k-th exact score is within the MFMA error bound of
 // what the candidate pool may have excluded (aux_kernels.hpp).  When the call may synchronise (host buffers, or
 // "margin_check" = 2) the flagged queries are re-scanned with the widest lists (K' = 32; 16 on an fp8 index): their
@@ -929,7 +1003,9 @@ int finish_margin(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, b
     ix->last_flagged = -1;
     ix->last_rescanned = 0;
     ix->last_unresolved = 0;
+    ix->first_nflag_dev = nullptr;
     if (ix->opt_margin == 0 || ix->rescan_depth != 0) return MIPS_OK;
+    if (out_dev && ix->opt_margin == 3) return rescan_on_stream<KL>(ix, nq, k, d_s, d_i, packed, idx_offset, st, fast_first);
     if (out_dev && ix->opt_margin != 2) return MIPS_OK; // counted on the device only: nothing here may synchronise
     if (!ix->nflag_host) HIP_TRY(hipHostMalloc((void**)&ix->nflag_host, 64, hipHostMallocDefault));
     HIP_TRY(hipMemcpyAsync(ix->nflag_host, ix->last_nflag_dev, 4, hipMemcpyDeviceToHost, st));
@@ -1366,7 +1442,7 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
         mips::fill_empty_kernel<<<(int)((total + 255) / 256), 256, 0, st>>>(d_s, d_i, packed ? d_i : nullptr, total, ix->call_metric);
         HIP_TRY(hipGetLastError());
         done = true;
-    } else if (tiny_eligible(ix, nq, k)) {
+    } else if (tiny_eligible(ix, nq, k) && !(out_dev && ix->opt_margin == 3)) { // (mode 3 re-scans on the stream: general path)
         // the reference's own call shape (<= 16 queries, small knowledge base): one launch (tiny_search.hpp)
         if (ix->call_metric == MIPS_METRIC_L2) {
             int rc = compute_phi(ix, st);
@@ -1435,7 +1511,7 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
         // (with K' = 8 pools 44 % of the queries of a Gaussian test set went to the second stage; pitch 1024 has no more).
         const bool hi_long = ix->hp > 0 && ix->hp <= 768;
         bool fast = ix->plane > 0 && ix->hp > 0 && (hi_long || k <= 7) && ix->opt_f32_fast != 0 && ix->opt_margin != 0 && !split &&
-                    (ix->opt_f32_fast == 2 || !out_dev || ix->opt_margin == 2);
+                    (ix->opt_f32_fast == 2 || !out_dev || ix->opt_margin >= 2);
         if (fast && ix->opt_f32_fast == 1 && ix->fast_skip > 0) {
             --ix->fast_skip;
             fast = false;
@@ -1462,7 +1538,7 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
             rc = scan_and_finish<10>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, tail_st, split, fast);
         } else if (k <= 13) {
             // bf16 index, a call that certifies: pool of 32 out of the 16x16x32 kernel's sub-lists (see mips_index::optimistic)
-            bool opt = ix->plane == 0 && ix->esize == 2 && ix->opt_margin != 0 && !split && (!out_dev || ix->opt_margin == 2) &&
+            bool opt = ix->plane == 0 && ix->esize == 2 && ix->opt_margin != 0 && !split && (!out_dev || ix->opt_margin >= 2) &&
                        ix->opt_f32_fast != 0 && ix->ld % 128 == 0 && ix->ld >= 384 && ix->ld <= 768;
             if (opt && ix->fast_skip > 0) {
                 --ix->fast_skip;
@@ -1682,7 +1758,7 @@ int mips_index_set_param(mips_index_t* ix, const char* name, int64_t value) {
         ix->opt_f32_fast = (int)value;
         ix->fast_skip = 0;
     } else if (n == "margin_check") {
-        if (value < 0 || value > 2) return fail(MIPS_E_INVALID, "mips_index_set_param: margin_check must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(MIPS_E_INVALID, "mips_index_set_param: margin_check must be 0, 1, 2 or 3");
         ix->opt_margin = (int)value;
     } else if (n == "spin_limit") ix->opt_spin_limit = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 30));
     else if (n == "sub") {
@@ -1711,7 +1787,17 @@ const char* mips_index_last_kernel(const mips_index_t* ix) { return ix ? ix->las
 int mips_index_margin_stats(mips_index_t* ix, int64_t* flagged, int64_t* rescanned, int64_t* unresolved, int synchronize,
                             void* hip_stream) {
     if (!ix) return fail(MIPS_E_INVALID, "mips_index_margin_stats: index is NULL");
-    if (ix->last_flagged < 0 && synchronize && ix->opt_margin != 0 && ix->last_nflag_dev != nullptr) {
+    if (ix->last_flagged < 0 && synchronize && ix->first_nflag_dev != nullptr) {
+        // the last search re-scanned its flagged queries on the stream: first count = flagged = re-scanned, second = unresolved
+        DeviceGuard g(ix->device);
+        unsigned n[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(&n[0], ix->first_nflag_dev, 4, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+        HIP_TRY(hipMemcpyAsync(&n[1], ix->last_nflag_dev, 4, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+        ix->last_flagged = (int64_t)n[0];
+        ix->last_rescanned = (int64_t)n[0];
+        ix->last_unresolved = (int64_t)n[1];
+    } else if (ix->last_flagged < 0 && synchronize && ix->opt_margin != 0 && ix->last_nflag_dev != nullptr) {
         // the last search only counted on the device: fetch the count now
         DeviceGuard g(ix->device);
         unsigned n = 0;

@@ -61,6 +61,8 @@ struct ScanArgs {
     unsigned* err;        // one word, zeroed per launch: set when a bounded spin gave up (never expected).  The exact
                           // re-score reads it and POISONS the call's output (idx -2, NaN) -- aux_kernels.hpp
     int spin_limit;       // polls of the split barrier before a wave gives up (1 << 22; tests shrink it to force the flag)
+    const int* nq_dev;    // stream-ordered re-scan ("margin_check" = 3): the query count lives on the device; nq / nqt
+                          // above are then upper bounds the launch was sized for, and workgroups past the count leave
     int plane;            // > 0: fp32-exact mode (generic kernel only).  Rows are two bf16 planes [hi | lo] of
                           // `plane` elements each (x = hi + lo up to 2^-17 relative) and the k-loop runs three
                           // segments hi.qhi + hi.qlo + lo.qhi; ld = 2 * plane, ksteps = 3 * plane / BK.
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_kernel(ScanArgs p) {
     const int qt = (xcd % p.qgroups) + p.qgroups * (j % p.qt_per_group);
     const int split = (xcd / p.qgroups) * p.splits_per_group + j / p.qt_per_group;
     if (qt >= p.nqt) return; // padding block of the last query group (whole workgroup leaves)
+    if (p.nq_dev != nullptr && qt * TN >= *p.nq_dev) return;
 
     const int t0 = split * p.tiles_per_split;
     int t1 = t0 + p.tiles_per_split;

@@ -55,8 +55,10 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_f8(ScanArgsF8 pa) {
     const int qt = (xcd % p.qgroups) + p.qgroups * (j % p.qt_per_group);
     const int split = (xcd / p.qgroups) * p.splits_per_group + j / p.qt_per_group;
     if (qt >= p.nqt) return;
+    const int nq_run = p.nq_dev != nullptr ? *p.nq_dev : p.nq; // (stream-ordered re-scan: the count is on the device)
+    if (qt * TN >= nq_run) return;
     if (p.spin_limit < 0 && tid == 0) *p.err = 1u; // test-only: force the scan-error path (include/mips_hip.h, "spin_limit")
-    const bool idle_wave = (qt * TN + wave * 32) >= p.nq;
+    const bool idle_wave = (qt * TN + wave * 32) >= nq_run;
 
     const int b0 = split * p.tiles_per_split;
     int b1 = b0 + p.tiles_per_split;

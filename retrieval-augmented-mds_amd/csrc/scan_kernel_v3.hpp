@@ -98,6 +98,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
     const int qt = (xcd % p.qgroups) + p.qgroups * (j % p.qt_per_group);
     const int split = (xcd / p.qgroups) * p.splits_per_group + j / p.qt_per_group;
     if (qt >= p.nqt) return;
+    const int nq_run = p.nq_dev != nullptr ? *p.nq_dev : p.nq; // (stream-ordered re-scan: the count is on the device)
+    if (qt * V3_TN >= nq_run) return;
     if (p.spin_limit < 0 && tid == 0) *p.err = 1u; // test-only: force the scan-error path (include/mips_hip.h, "spin_limit")
 
     const int b0 = split * p.tiles_per_split; // "tiles" are 32-document blocks here
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_kernel_v3(ScanArgs
     // without work) still brings its share of every document block and takes part in the block barrier, but skips
     // the MFMA chain and the epilogue: fewer issue slots and less power spent next to the document stream, which is all
     // that matters in this HBM-bound regime.
-    const bool idle_wave = (qt * V3_TN + wave * NQB * 32) >= p.nq;
+    const bool idle_wave = (qt * V3_TN + wave * NQB * 32) >= nq_run;
 
     // ---- stationary query fragments: lane holds Q[q0 + l31][16 s + 8 h .. +8) for every k16-step s
     bf16x8 bq[NQB][KS16];

@@ -270,7 +270,7 @@ class MipsIndex:
     def margin_stats(self, synchronize: bool = True) -> dict:
         """Margin check of the LAST search (include/mips_hip.h, mips_index_margin_stats): {"flagged": queries whose
         candidate pool was not provably wide enough, "rescanned": of those re-scanned with the widest lists,
-        "unresolved": still flagged}.  set_param("margin_check", 0 | 1 | 2) selects off / count only (default for
+        "unresolved": still flagged}.  set_param("margin_check", 0 | 1 | 2 | 3) selects off / count only (default for
         device tensors) / certify (synchronise + re-scan; NumPy searches always do)."""
         f, r, u = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         _lib.check(self._lib.mips_index_margin_stats(self._h, ctypes.byref(f), ctypes.byref(r), ctypes.byref(u),

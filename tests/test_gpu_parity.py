@@ -1454,10 +1454,72 @@ def test_near_duplicates_crowding_one_sub_list_are_certified(nq):
     assert np.array_equal(di.cpu().numpy()[free], fi)
     pk = ix.search_packed(qd, k, 500)                         # the packed payload is patched the same way
     assert np.array_equal(pk[..., 1].cpu().numpy()[stars], ei + 500)
+    # ... or certified WITHOUT a synchronisation: the re-scan is enqueued behind the first scan, sized for all queries,
+    # and reads the flagged count on the device (mode 3); a graph replay does the same
+    ix.set_param("margin_check", 3)
+    for rep in range(3):
+        ds, di = ix.search(qd, k)
+    st3 = ix.margin_stats()
+    assert st3 == st, (st3, st)
+    assert np.array_equal(di.cpu().numpy()[stars], ei) and np.array_equal(ds.cpu().numpy()[stars], es)
+    assert np.array_equal(di.cpu().numpy()[free], fi) and np.array_equal(ds.cpu().numpy()[free], fs)
+    pk = ix.search_packed(qd, k, 500)
+    assert np.array_equal(pk[..., 1].cpu().numpy()[stars], ei + 500) and np.array_equal(pk[..., 1].cpu().numpy()[free], fi + 500)
+    g = torch.cuda.CUDAGraph()
+    buf = qd.clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ix.search(buf, k)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        gs, gi = ix.search(buf, k)
+    buf.copy_(qd.flip(0))                                     # other queries through the captured launches
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(gi.flip(0).cpu().numpy()[stars], ei) and np.array_equal(gi.flip(0).cpu().numpy()[free], fi)
     # off: no flags, no statistics
     ix.set_param("margin_check", 0)
     ix.search(q, k)
     assert ix.margin_stats()["flagged"] in (-1, 0)
+
+
+def test_stream_ordered_certification_opens_the_fast_paths_to_device_outputs():
+    """ "margin_check" = 3: device-output searches certify without synchronising, so they may take the paths that depend on
+    the certificate -- optimistic pools for 8 <= k <= 13 and the two-stage search of the fp32-exact index -- and stay exact
+    where those paths flag nearly everything (near-duplicate clusters)."""
+    x = synth.generate(411, 0, 40000, 768, synth.KIND_GAUSS)
+    q = synth.generate(412, 0, 500, 768, synth.KIND_GAUSS)
+    qd = torch.from_numpy(q).cuda()
+    es, ei = orc.search_exact(q, x, 10)
+    ix = _index(x)
+    ix.set_param("margin_check", 3)
+    s, i = ix.search(qd, 10)
+    assert ix.last_kernel.startswith("mips::scan_kernel_v4") and ix.last_kernel.endswith(", 4>")
+    assert np.array_equal(i.cpu().numpy(), ei) and np.array_equal(s.cpu().numpy(), es)
+    assert ix.margin_stats()["unresolved"] == 0
+    # fp32-exact index, clustered rows
+    rng = np.random.default_rng(5)
+    c = rng.standard_normal((300, 768)).astype(np.float32)
+    y = (np.repeat(c, 40, axis=0) * (1.0 + 1e-4 * rng.standard_normal((12000, 1)))).astype(np.float32)
+    y += (1e-4 * rng.standard_normal(y.shape)).astype(np.float32)
+    qq = (c[rng.integers(0, 300, 200)] + 0.01 * rng.standard_normal((200, 768))).astype(np.float32)
+    es, ei = orc.search_exact(qq, y, 5)
+    f = ram.MipsIndex(768, dtype="f32")
+    f.add(y)
+    f.set_param("margin_check", 3)
+    s, i = f.search(torch.from_numpy(qq).cuda(), 5)
+    assert not f.last_kernel.startswith("mips::scan_kernel<")        # stage 1 on the bf16 rows
+    st = f.margin_stats()
+    assert st["flagged"] > 50 and st["rescanned"] == st["flagged"], st   # (40 members within 1e-4 of each other: the widest
+    assert np.array_equal(i.cpu().numpy(), ei) and np.array_equal(s.cpu().numpy(), es)   # lists cannot CERTIFY these either)
+    g = rng.standard_normal((30000, 768)).astype(np.float32)            # well-separated rows: nothing to re-scan
+    qg = rng.standard_normal((300, 768)).astype(np.float32)
+    f2 = ram.MipsIndex(768, dtype="f32")
+    f2.add(g)
+    f2.set_param("margin_check", 3)
+    s, i = f2.search(torch.from_numpy(qg).cuda(), 5)
+    es, ei = orc.search_exact(qg, g, 5)
+    assert np.array_equal(i.cpu().numpy(), ei) and np.array_equal(s.cpu().numpy(), es) and f2.margin_stats()["flagged"] == 0
 
 
 def test_margin_check_on_ordinary_data_flags_few_and_changes_nothing():
