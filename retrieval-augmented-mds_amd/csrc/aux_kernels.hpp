@@ -623,6 +623,7 @@ __device__ __forceinline__ void rescore_rank_body(const MergeArgs& p, const int*
     const bool inq = q < nq && lane < QPW * KL; // K' = 10: lanes 60..63 belong to no query
     if (p.err != nullptr && *p.err != 0u) { // the scan gave up on its barrier: nothing below can be trusted
         if (wave_index == 0 && lane == 0) __hip_atomic_store(p.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (inq && slot == 0 && p.flag != nullptr) p.flag[q] = 0; // (nothing to re-scan: a stream-ordered re-scan must not touch the poison)
         if (inq && slot < p.k) {
             const size_t o = (size_t)q * p.k + slot;
             if (p.out_packed) {

@@ -1098,6 +1098,20 @@ def test_scan_timeout_poisons_and_raises_on_every_path():
         ix.check()
         assert torch.equal(i, ref_i) and torch.equal(s, ref_s)
     ix.set_param("spin_limit", 0)
+    # stream-ordered certification ("margin_check" = 3) enqueues a re-scan behind every search: it must not touch the poison
+    ix.set_param("margin_check", 3)
+    ix.search(q, k)
+    ix.set_param("spin_limit", -1)
+    s, i = ix.search(q, k)
+    torch.cuda.synchronize()
+    assert (i == ram.IDX_POISON).all() and torch.isnan(s).all()
+    with pytest.raises(RuntimeError, match="gave up"):
+        ix.check()
+    ix.set_param("spin_limit", 0)
+    s, i = ix.search(q, k)
+    ix.check()
+    assert torch.equal(i, ref_i) and torch.equal(s, ref_s)
+    ix.set_param("margin_check", 1)
     # merge kernels: one poisoned shard poisons the merged rows
     good = ix.search_packed(q, k, 0)
     bad = good.clone()

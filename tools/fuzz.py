@@ -60,11 +60,11 @@ while time.time() < t_end:
     if rng.random() < 0.15:
         knobs["tiny"] = 0
     if rng.random() < 0.3:
-        knobs["margin_check"] = int(rng.choice([0, 2]))
+        knobs["margin_check"] = int(rng.choice([0, 2, 3, 3]))
     if rng.random() < 0.2:
         knobs["qgroups"] = int(rng.choice([1, 2, 4, 8]))
-    if dtype == "f32" and rng.random() < 0.5:
-        knobs["f32_fast"] = int(rng.choice([0, 1]))                  # (2 only counts what it cannot certify on device outputs)
+    if rng.random() < 0.3:
+        knobs["optimistic"] = int(rng.choice([0, 1]))                # two-stage fp32 search / optimistic pools (2 would only count on device outputs)
     for name, v in knobs.items():
         ix.set_param(name, v)
     dev = bool(rng.random() < 0.4)                                     # CUDA tensors in / out instead of NumPy
