@@ -185,6 +185,16 @@ class ShardedMipsIndex:
             self._sync_phi()  # files written before phi was persisted
         return self
 
+    def set_param(self, name: str, value: int) -> None:
+        """Knob of the LOCAL scan (MipsIndex.set_param) -- every rank sets its own.  `set_param("margin_check", 3)` makes the
+        local device-output searches certify without synchronising (stream-ordered re-scan of the queries they flag), which
+        also opens the optimistic / two-stage paths (8 <= k <= 13, fp32-exact shards) to the sharded search."""
+        self.local.set_param(name, value)
+
+    def margin_stats(self, synchronize: bool = True) -> dict:
+        """Margin statistics of the last LOCAL search (MipsIndex.margin_stats)."""
+        return self.local.margin_stats(synchronize)
+
     def check(self, synchronize: bool = True) -> None:
         """MipsIndex.check for this rank's shard.  A shard whose scan timed out hands poisoned rows (idx -2, NaN)
         to the all-gather and the merge kernel propagates them, so every rank SEES the failure in its results;

@@ -395,8 +395,15 @@ def _rank_worker(rank, world, port, n, nq, d, k, ret):
         x = synth.generate(synth.SEED_DOCS, 0, n, d, synth.KIND_GAUSS)
         es, ei = orc.search_exact(q.float().cpu().numpy(), x, k)
         lo, hi = ram.shard_bounds(n, world, rank)
-        ret[rank] = bool(np.array_equal(i.cpu().numpy(), ei) and np.array_equal(s.cpu().numpy(), es)
-                         and ix.local.ntotal == hi - lo)
+        ok = bool(np.array_equal(i.cpu().numpy(), ei) and np.array_equal(s.cpu().numpy(), es) and ix.local.ntotal == hi - lo)
+        # k = 10 with stream-ordered certification: every shard scans with optimistic pools, nothing synchronises before the exchange
+        ix.set_param("margin_check", 3)
+        s10, i10 = ix.search(q, 10)
+        torch.cuda.synchronize()
+        es10, ei10 = orc.search_exact(q.float().cpu().numpy(), x, 10)
+        ok = ok and bool(np.array_equal(i10.cpu().numpy(), ei10) and np.array_equal(s10.cpu().numpy(), es10))
+        ok = ok and ix.local.last_kernel.startswith("mips::scan_kernel_v4") and ix.margin_stats()["unresolved"] == 0
+        ret[rank] = ok
     finally:
         dist.destroy_process_group()
 
