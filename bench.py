@@ -19,7 +19,8 @@ RCCL all-gather + merge produces the replicated global top-k: total work is fixe
 One JSON line on rank 0.  `roofline` describes the dominant kernel (the fused scan; its name comes from the
 library: mips_index_last_kernel): this workload has Q = 4096 flop per index byte, far above the ~310 flop/B
 ridge, so the binding roof is MFMA; the HBM-read fraction the north star asks for is reported next to it
-(hbm_* keys) and measured where it is meaningful in `regimes` (2^24 x 768 index at Q = 8: HBM-bound).
+(hbm_* keys) and measured where it is meaningful in `regimes` (2^24 x 768 index at Q = 8: HBM-bound; `regimes` also carries
+the fp32-exact index and k = 10 at the headline's size: the paths that rest on the per-query certificate).
 `cpu_baseline` times the oracle's literal restatement of the reference's brute force (sotasum/mips.py:552-560:
 fp32 matmul + full argsort), `cpu_baseline_torch` the reference's CPU torch idiom (retriever_lightning.py:304-305,
 `topk(q @ d.T)`) on all host cores; rank 0, N = 1 only, bounded samples, >= 3 repeats, median.
@@ -182,6 +183,40 @@ def regime(ram, torch, rows, d, nq, k, dtype, device, iters):
         })
     del ix
     torch.cuda.empty_cache()
+    return out
+
+
+def regime_certified(ram, torch, rows, d, nq, device, iters=5):
+    """Two more points of the same run, same index size as the headline: paths that rest on the per-query certificate
+    (device outputs, default margin mode = stream-ordered re-scan of flagged queries, nothing synchronises) --
+    the fp32-exact index (the reference's own dtype) through the two-stage search, and k = 10 through optimistic pools."""
+    out = []
+    g = torch.Generator(device=f"cuda:{device}").manual_seed(0xD0C5)
+    for dtype, k in (("f32", 5), ("bf16", 10)):
+        ix = ram.MipsIndex(d, dtype=dtype, device=device)
+        ix.reserve(rows)
+        if dtype == "f32":  # rows that are NOT bf16-representable (the synthetic generator emits bf16 values)
+            for r0 in range(0, rows, 1 << 18):
+                ix.add(torch.randn(min(1 << 18, rows - r0), d, device=f"cuda:{device}", generator=g))
+            q = torch.randn(nq, d, device=f"cuda:{device}", generator=g)
+        else:
+            ix.add_synthetic(rows, 0, ram.SEED_DOCS, ram.SYNTH_GAUSS)
+            q = ram.synth_fill(nq, d, 0, ram.SEED_QUERIES, ram.SYNTH_GAUSS, dtype="bf16", device=device)
+        for _ in range(2):
+            ix.search(q, k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            ix.search(q, k)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / iters
+        ix.check()
+        st = ix.margin_stats()
+        out.append({"workload": f"{rows}x{d} {'fp32-exact' if dtype == 'f32' else 'bf16'} index, Q={nq}, k={k}, device outputs, certified on the stream",
+                    "queries_per_s": nq / wall, "call_ms": wall * 1e3, "kernel": ix.last_kernel, "flagged": st["flagged"],
+                    "rescanned": st["rescanned"], "unresolved": st["unresolved"]})
+        del ix
+        torch.cuda.empty_cache()
     return out
 
 
@@ -417,6 +452,7 @@ def main():
         free_b, _ = torch.cuda.mem_get_info()
         if free_b > 40e9:
             regimes = regime(ram, torch, 1 << 24, 768, [4096, 8], k, "bf16", local_rank, [5, 20])
+            regimes += regime_certified(ram, torch, n, d, nq, local_rank)
 
     if rank == 0:
         out = {

@@ -94,9 +94,9 @@ const char* mips_last_error(void);
  *   MIPS_DTYPE_FP8_E4M3  1 B/element, inputs AND queries rounded to OCP e4m3 (d <= 1024, k <= 13)
  *   MIPS_DTYPE_F32       fp32-exact: results are those of an fp32 brute force on the caller's values
  *                        (bf16 hi|lo planes for the three-segment scan + the fp32 rows for the exact re-score, 8 B/element;
- *                        for d <= 1024 also bf16(x) alone at the fast kernels' row pitch, + 2 B/element: searches with
- *                        k <= 7 that may synchronise (host buffers, or "margin_check" = 2) scan THAT like a bf16 index,
- *                        re-score on the fp32 rows, and send only the queries whose margin -- widened by the
+ *                        for d <= 1024 also bf16(x) alone at the fast kernels' row pitch, + 2 B/element: searches that
+ *                        certify (host buffers; device outputs re-scan on the stream, see mips_index_margin_stats) scan
+ *                        THAT like a bf16 index, re-score on the fp32 rows, and send only the queries whose margin -- widened by the
  *                        representation error |x - bf16 x| |q| + |bf16 x| |q - bf16 q| -- is not certified through the
  *                        three-segment scan: same results, ~3x the rate on well-separated data; "f32_fast" below). */
 int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, int metric);
@@ -277,7 +277,9 @@ int mips_index_check_error(mips_index_t* index, int synchronize, void* hip_strea
  * bound, documents dropped from a full running list) and FLAGS the query when B + e >= tk, e = d 2^-23 |q| max|x|
  * (a rigorous bound for fp32 accumulation of the exact bf16 / e4m3 products).  "margin_check" (mips_index_set_param):
  *   0  off;
- *   1  (default) flag and count on the device -- nothing synchronises; read the count with this call;
+ *   1  (default) flag and count on the device -- nothing synchronises; read the count with this call.  Exception: where
+ *      a certificate buys a faster scan (fp32-exact index; 8 <= k <= 13 on a bf16 index at row pitch 384 .. 768) device-output
+ *      searches behave as in mode 3 -- still without synchronising; "f32_fast" = 0 keeps them on the plain scans;
  *   2  certify: mips_search synchronises and re-scans the flagged queries with the widest lists (K' = 32; 16 on an
  *      fp8 index), overwriting their rows.  Searches into HOST buffers synchronise anyway and always do this unless
  *      the check is off.

@@ -1468,6 +1468,21 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
             done = ix->last_flagged == 0;
         }
     }
+    // Default margin mode (1 = count only): where a certificate buys a faster scan -- fp32-exact index (two-stage search),
+    // 8 <= k <= 13 on a bf16 index (optimistic pools) -- device-output searches certify on the stream (mode 3) instead.
+    struct MarginScope {
+        mips_index* ix;
+        int keep;
+        ~MarginScope() { ix->opt_margin = keep; }
+    } margin_scope{ix, ix->opt_margin};
+    if (!done && ix->opt_margin == 1 && out_dev && !split && ix->opt_f32_fast == 1) {
+        const bool two_stage = ix->plane > 0 && ix->hp > 0 && (ix->hp <= 768 || k <= 7);
+        const bool pools = ix->plane == 0 && ix->esize == 2 && k >= 8 && k <= 13 && ix->ld % 128 == 0 && ix->ld >= 384 && ix->ld <= 768;
+        if (two_stage || pools) {
+            if (ix->fast_skip > 0) --ix->fast_skip; // (a recent call flagged too much for the fast scan to pay: plain mode 1)
+            else ix->opt_margin = 3;
+        }
+    }
     if (!done) {
         if (ix->call_metric == MIPS_METRIC_L2) {
             int rc = compute_phi(ix, st);

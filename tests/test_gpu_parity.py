@@ -915,14 +915,23 @@ def test_f32_exact_two_stage_search(n, nq, d, k, metric):
     print("two-stage:", n, nq, d, k, metric, ix.last_kernel, st)
     assert st["flagged"] < (nq // 2 if d > 768 else max(2, nq // 10))   # Gaussian rows: stage 1 certifies nearly all (K' = 32 pools)
     qd = torch.from_numpy(q).cuda()
-    sd, idd = ix.search(qd, k)                                    # device outputs: one-stage (nothing may synchronise)
+    sd, idd = ix.search(qd, k)                                    # device outputs: two-stage as well, certified on the stream
+    if d <= 768:                                                  # (pitch 1024: pools of 8 flag too much, stage 1 is being skipped)
+        assert not ix.last_kernel.startswith("mips::scan_kernel<")   # default margin mode: nothing synchronises
+        st_d = ix.margin_stats()
+        assert st_d["rescanned"] == st_d["flagged"] and st_d["unresolved"] == 0
+    assert np.array_equal(idd.cpu().numpy(), ei) and np.array_equal(sd.cpu().numpy(), es)
+    ix.set_param("margin_check", 0)                               # no certificate, no two-stage search
+    sd, idd = ix.search(qd, k)
     assert ix.last_kernel.startswith("mips::scan_kernel<")
     assert np.array_equal(idd.cpu().numpy(), ei) and np.array_equal(sd.cpu().numpy(), es)
-    ix.set_param("f32_fast", 2)
+    ix.set_param("margin_check", 1)
+    ix.set_param("f32_fast", 2)                                   # forced: stage 1 even where flagged queries are only counted
+    ix.set_param("margin_check", 1)
     sd, idd = ix.search(qd, k)
     assert not ix.last_kernel.startswith("mips::scan_kernel<")
     rows_ok = (idd.cpu().numpy() == ei).all(axis=1)
-    assert rows_ok.sum() >= nq - ix.margin_stats()["flagged"]     # every certified query is exact
+    assert rows_ok.sum() >= nq - max(0, ix.margin_stats()["flagged"])     # every certified query is exact
     ix.set_param("f32_fast", 0)
     s0, i0 = ix.search(q, k)
     assert ix.last_kernel.startswith("mips::scan_kernel<") and np.array_equal(i0, ei) and np.array_equal(s0, es)
@@ -943,9 +952,14 @@ def test_optimistic_pools_for_k_8_to_13(n, nq, d, k):
     print("optimistic:", n, nq, d, k, ix.last_kernel, st)
     assert np.array_equal(i, ei) and np.array_equal(s, es)
     assert st["unresolved"] == 0 and st["rescanned"] == st["flagged"]
-    sd, idd = ix.search(torch.from_numpy(q).cuda(), k)           # device outputs: true K' = 16 lists
+    sd, idd = ix.search(torch.from_numpy(q).cuda(), k)           # device outputs: the same, certified on the stream
+    assert ix.last_kernel.startswith("mips::scan_kernel_v4")
+    assert np.array_equal(idd.cpu().numpy(), ei) and np.array_equal(sd.cpu().numpy(), es)
+    ix.set_param("margin_check", 0)                               # no certificate: true K' = 16 lists
+    sd, idd = ix.search(torch.from_numpy(q).cuda(), k)
     assert not ix.last_kernel.startswith("mips::scan_kernel_v4")
     assert np.array_equal(idd.cpu().numpy(), ei) and np.array_equal(sd.cpu().numpy(), es)
+    ix.set_param("margin_check", 1)
     ix.set_param("optimistic", 0)
     s0, i0 = ix.search(q, k)
     assert not ix.last_kernel.startswith("mips::scan_kernel_v4") and np.array_equal(i0, ei) and np.array_equal(s0, es)
