@@ -414,6 +414,8 @@ struct MergeArgs {
     const double* dres2 = nullptr; // device scalar: max_i |x_i - bf16(x_i)|^2 over the stored rows
     const double* qerr2 = nullptr; // [nq]: |q - bf16(q)|^2
     const int* nq_dev = nullptr;   // stream-ordered re-scan: the query count lives on the device (launches sized for the maximum)
+    float* keyk = nullptr;         // [nq] out: canonical key of the k-th result (+inf: fewer than k results) -- resolve_kernels.hpp
+    double* qq_out = nullptr;      // [nq] out: |q|^2 as the re-score summed it
 };
 
 // What a search whose scan kernel gave up (split-barrier spin bound, scan_kernel_v3.hpp) returns instead of
@@ -575,6 +577,10 @@ __device__ __forceinline__ void rank_flag_write(const MergeArgs& p, int64_t q, i
                     have = true;
                 }
             }
+        }
+        if (inq && slot == 0 && p.keyk != nullptr) {
+            p.keyk[q] = have ? (L2 ? -(float)(qn + p.phi - 2.0 * tk) : (float)tk) : INFINITY;
+            p.qq_out[q] = qn;
         }
         if (inq && slot == 0) {
             const float b = p.bnd[q];

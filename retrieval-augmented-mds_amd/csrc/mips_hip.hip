@@ -22,6 +22,7 @@
 #include "scan_kernel_v5.hpp"
 #include "scan_kernel_ks.hpp"
 #include "tiny_search.hpp"
+#include "resolve_kernels.hpp"
 
 namespace {
 
@@ -127,6 +128,7 @@ struct mips_index {
     // compacted on the device and the second scan, sized for all queries, lets the workgroups past the count leave
     const int* nq_dev = nullptr;         // launch_search: device-side query count of the re-scan in progress
     const int* first_nflag_dev = nullptr; // flagged count of the first scan of the last mode-3 search (margin stats)
+    int64_t stats_nq = 0;                 // queries of the last search whose resolve statistics went to sticky_host[2..3]
     int plane_keep = 0;
     int fast_skip = 0;           // calls left to skip stage 1 for (the last one flagged too many queries to pay)
     bool phi_valid = false;
@@ -151,7 +153,8 @@ struct mips_index {
     // synchronise, re-scan the flagged queries with the widest lists.  Host-output searches always certify (they
     // synchronise anyway) unless the check is off.
     int opt_margin = 1;
-    Buffer mbnd, mflag, qbuf2, qf32b, tmp_s, tmp_i, ids, qhi, qerr2;
+    Buffer mbnd, mflag, qbuf2, qf32b, tmp_s, tmp_i, ids, qhi, qerr2, keyk, qqv, hit_d, hit_i, hit_n;
+    int opt_resolve = 1; // flagged queries: 1 = exact brute-force resolution (resolve_kernels.hpp), 0 = re-scan with the widest lists
     double* xmax2_dev = nullptr; // max_i |x_i|^2 of the LOCAL rows, on the device (no host copy: never synchronises)
     bool xmax2_valid = false;
     unsigned* nflag_host = nullptr; // pinned: flagged-query count of the last certified search
@@ -774,6 +777,14 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         m.flag = (unsigned char*)ix->mflag.p;
         m.nflag = (unsigned*)ix->gthr.p + (size_t)nq_pad * 8 + 1; // zeroed with the insert bounds by the query staging
         ix->last_nflag_dev = m.nflag;
+        if (ix->rescan_depth == 0) { // what the exact resolution of flagged queries starts from (resolve_kernels.hpp)
+            rc = ix->keyk.ensure((size_t)nq * sizeof(float));
+            if (rc) return rc;
+            rc = ix->qqv.ensure((size_t)nq * sizeof(double));
+            if (rc) return rc;
+            m.keyk = (float*)ix->keyk.p;
+            m.qq_out = (double*)ix->qqv.p;
+        }
     }
     // (1) K' best candidates per query by MFMA score, (2) lane-packed exact re-score + final order
     rc = ix->cand.ensure((size_t)nq * KL * sizeof(int));
@@ -924,6 +935,90 @@ int tiny_search(mips_index* ix, const void* q_dev, int q_dtype, int64_t nq, int 
     return MIPS_OK;
 }
 
+// Exact resolution of the flagged queries (resolve_kernels.hpp): flag list + count on the device, one pass over the stored
+// rows per 8 flagged queries computing canonical scores, the hit lists ranked over the first results.
+// certify_now: the call synchronises anyway (host buffers / "margin_check" = 2): the count is read first, and a search that
+// flagged more than RESOLVE_MAX queries is handed to the tile re-scan (return value kUseRescan).  Otherwise everything is
+// enqueued blind; the counts travel to host-visible words for the next search to look at (mips_index::stats_host).
+constexpr int kUseRescan = 1;
+int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, bool packed, int64_t idx_offset, hipStream_t st, bool certify_now) {
+    int rc = ix->ids.ensure((size_t)(nq + 4) * sizeof(int));
+    if (rc) return rc;
+    int* ids = (int*)ix->ids.p;
+    int* cnt = ids + nq;
+    unsigned* unres = (unsigned*)(ids + nq + 1);
+    rc = ix->hit_d.ensure((size_t)mips::RESOLVE_MAX * mips::RESOLVE_CAP * sizeof(double));
+    if (rc) return rc;
+    rc = ix->hit_i.ensure((size_t)mips::RESOLVE_MAX * mips::RESOLVE_CAP * sizeof(int));
+    if (rc) return rc;
+    rc = ix->hit_n.ensure((size_t)mips::RESOLVE_MAX * sizeof(int));
+    if (rc) return rc;
+    if (!ix->nflag_host) HIP_TRY(hipHostMalloc((void**)&ix->nflag_host, 64, hipHostMallocDefault));
+    mips::compact_flags_kernel<<<1, 256, 0, st>>>((const unsigned char*)ix->mflag.p, (int)nq, ids, cnt);
+    HIP_TRY(hipMemsetAsync(unres, 0, sizeof(unsigned), st));
+    if (certify_now) {
+        HIP_TRY(hipMemcpyAsync(&ix->nflag_host[0], cnt, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const int64_t n = (int64_t)ix->nflag_host[0];
+        ix->last_flagged = n;
+        ix->last_rescanned = 0;
+        ix->last_unresolved = 0;
+        if (n == 0) return MIPS_OK;
+        if (n > mips::RESOLVE_MAX) return kUseRescan;
+    }
+    HIP_TRY(hipMemsetAsync(ix->hit_n.p, 0, (size_t)mips::RESOLVE_MAX * sizeof(int), st));
+    mips::ResolveArgs a;
+    const bool f32x = ix->plane > 0;
+    a.rows = f32x ? (const void*)ix->rows_f32 : (const void*)ix->rows;
+    a.y = f32x ? (const void*)ix->qf32.p : (const void*)ix->qbuf.p;
+    a.ld = f32x ? ix->plane : ix->ld;
+    a.ntotal = ix->ntotal;
+    a.ids = ids;
+    a.n_dev = cnt;
+    a.keyk = (const float*)ix->keyk.p;
+    a.qq = (const double*)ix->qqv.p;
+    a.phi = ix->phi;
+    a.hit_d = (double*)ix->hit_d.p;
+    a.hit_i = (int*)ix->hit_i.p;
+    a.hit_n = (int*)ix->hit_n.p;
+    a.k = k;
+    a.idx_offset = idx_offset;
+    a.out_s = d_s;
+    a.out_i = d_i;
+    a.out_packed = packed ? d_i : nullptr;
+    a.unresolved = unres;
+    const int lds = mips::RESOLVE_QB * a.ld * (int)sizeof(double) + 4 * 64 * 9 * 16;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (ix->ntotal + 255) / 256));
+    const bool l2 = ix->call_metric == MIPS_METRIC_L2;
+    auto go = [&](auto kern) -> int {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        kern<<<grid, 256, lds, st>>>(a);
+        return MIPS_OK;
+    };
+    if (f32x) rc = l2 ? go(mips::exact_filter_kernel<mips::ElemF32, true>) : go(mips::exact_filter_kernel<mips::ElemF32, false>);
+    else if (ix->esize == 1) rc = l2 ? go(mips::exact_filter_kernel<mips::ElemF8, true>) : go(mips::exact_filter_kernel<mips::ElemF8, false>);
+    else rc = l2 ? go(mips::exact_filter_kernel<mips::ElemBF16, true>) : go(mips::exact_filter_kernel<mips::ElemBF16, false>);
+    if (rc) return rc;
+    const int fgrid = (int)std::min<int64_t>(nq, certify_now ? (int64_t)ix->nflag_host[0] : nq);
+    if (l2) mips::resolve_finalize_kernel<true><<<fgrid, 64, 0, st>>>(a);
+    else mips::resolve_finalize_kernel<false><<<fgrid, 64, 0, st>>>(a);
+    HIP_TRY(hipGetLastError());
+    ix->first_nflag_dev = (const int*)cnt;
+    ix->last_nflag_dev = unres;
+    if (certify_now) {
+        HIP_TRY(hipMemcpyAsync(&ix->nflag_host[1], unres, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        ix->last_rescanned = ix->last_flagged;
+        ix->last_unresolved = (int64_t)ix->nflag_host[1];
+    } else {
+        ix->last_flagged = -1;
+        ix->stats_nq = nq;
+        mips::publish_resolve_stats_kernel<<<1, 1, 0, st>>>(cnt, unres, ix->sticky_dev + 2);
+        HIP_TRY(hipGetLastError());
+    }
+    return MIPS_OK;
+}
+
 // "margin_check" = 3, device outputs: the re-scan of finish_margin without its two synchronisations.  The flags of the first
 // scan are compacted into a list + count ON THE DEVICE; the staged rows of the flagged queries are gathered; the second scan
 // (widest lists) is launched for ALL nq queries' worth of workgroups, which read the count and leave when they are past it
@@ -968,7 +1063,7 @@ int rescan_on_stream(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i
     ix->rescan_depth = 1;
     ix->nq_dev = cnt;
     const int ns_keep = ix->opt_nsplit;
-    if (ns_keep == 0 && nq <= 8192) ix->opt_nsplit = 64; // the flagged queries are few: spread each of their tiles over many CUs
+    if (ns_keep == 0 && nq <= 8192) ix->opt_nsplit = nq <= 4096 ? 128 : 64; // the flagged queries are few: spread each of their tiles over many CUs
     float* ts = (float*)ix->tmp_s.p;
     int64_t* ti = (int64_t*)ix->tmp_i.p;
     if (wide == 32) rc = launch_search<32>(ix, nq, k, ts, ti, packed ? ti : nullptr, idx_offset, st, nullptr, false);
@@ -1005,8 +1100,16 @@ int finish_margin(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, b
     ix->last_unresolved = 0;
     ix->first_nflag_dev = nullptr;
     if (ix->opt_margin == 0 || ix->rescan_depth != 0) return MIPS_OK;
-    if (out_dev && ix->opt_margin == 3) return rescan_on_stream<KL>(ix, nq, k, d_s, d_i, packed, idx_offset, st, fast_first);
-    if (out_dev && ix->opt_margin != 2) return MIPS_OK; // counted on the device only: nothing here may synchronise
+    if (out_dev && ix->opt_margin != 2 && ix->opt_margin != 3) return MIPS_OK; // counted on the device only
+    // flagged queries are settled exactly, by brute force on the canonical scores (rows of up to 1024 columns; beyond that
+    // -- and with "resolve" = 0 -- by the re-scan with the widest lists below)
+    if (ix->opt_resolve != 0 && (ix->plane > 0 ? ix->plane : ix->ld) <= 1024) {
+        const int r = resolve_flagged(ix, nq, k, d_s, d_i, packed, idx_offset, st, !(out_dev && ix->opt_margin == 3));
+        if (r != kUseRescan) return r;
+        ix->first_nflag_dev = nullptr; // (more flagged than the exact pass takes: the tile re-scan below, which synchronises)
+    } else if (out_dev && ix->opt_margin == 3) {
+        return rescan_on_stream<KL>(ix, nq, k, d_s, d_i, packed, idx_offset, st, fast_first);
+    }
     if (!ix->nflag_host) HIP_TRY(hipHostMalloc((void**)&ix->nflag_host, 64, hipHostMallocDefault));
     HIP_TRY(hipMemcpyAsync(ix->nflag_host, ix->last_nflag_dev, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1061,10 +1164,15 @@ int finish_margin(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, b
     std::memcpy(name_keep, ix->last_kernel, sizeof name_keep);
     ix->timing_armed = false; // the bench's event window times the first scan only
     ix->rescan_depth = 1;
+    // few flagged queries = few query tiles: spread each tile's scan over many more splits than the automatic choice makes
+    // (it stops at 64; one 128-query tile of the three-segment scan on 64 workgroups took 17 ms at 2^20 x 768)
+    const int ns_keep = ix->opt_nsplit;
+    if (ns_keep == 0 && n <= 1024) ix->opt_nsplit = (int)std::max<int64_t>(64, std::min<int64_t>(256, round_up(512 / ((n + 127) / 128), 8)));
     float* ts = (float*)ix->tmp_s.p;
     int64_t* ti = (int64_t*)ix->tmp_i.p;
     if (wide == 32) rc = launch_search<32>(ix, n, k, ts, ti, packed ? ti : nullptr, idx_offset, st);
     else rc = launch_search<16>(ix, n, k, ts, ti, packed ? ti : nullptr, idx_offset, st);
+    ix->opt_nsplit = ns_keep;
     ix->rescan_depth = 0;
     ix->timing_armed = armed;
     std::memcpy(ix->last_kernel, name_keep, sizeof name_keep);
@@ -1122,7 +1230,7 @@ int scan_and_finish(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
     rc = finish_margin<KL>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, first_was_optimistic);
     // the optimistic scan pays while few queries need the second one: after a call that sent more than a quarter there, skip
     // it for a while
-    if (!rc && first_was_optimistic && ix->opt_f32_fast != 2 && ix->last_flagged >= 16 && ix->last_flagged * 4 > nq) ix->fast_skip = 8;
+    if (!rc && first_was_optimistic && ix->opt_f32_fast != 2 && ix->last_flagged >= 64 && ix->last_flagged * 8 > nq) ix->fast_skip = 8;
     return rc;
 }
 
@@ -1190,7 +1298,7 @@ int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, 
         mips_index_destroy(ix);
         return fail(MIPS_E_HIP, "hipHostMalloc for the scan-error word failed");
     }
-    *ix->sticky_host = 0u;
+    for (int w = 0; w < 16; ++w) ix->sticky_host[w] = 0u; // [0] scan error, [2..3] resolve statistics of the last stream-ordered search
     *out = ix;
     return MIPS_OK;
 }
@@ -1225,6 +1333,11 @@ int mips_index_destroy(mips_index_t* ix) {
     if (ix->dres2_dev) (void)hipFree(ix->dres2_dev);
     ix->qhi.release();
     ix->qerr2.release();
+    ix->keyk.release();
+    ix->qqv.release();
+    ix->hit_d.release();
+    ix->hit_i.release();
+    ix->hit_n.release();
     for (int e = 0; e < mips_index::kEvRing; ++e) {
         if (ix->ev0[e]) (void)hipEventDestroy(ix->ev0[e]);
         if (ix->ev1[e]) (void)hipEventDestroy(ix->ev1[e]);
@@ -1475,6 +1588,15 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
         int keep;
         ~MarginScope() { ix->opt_margin = keep; }
     } margin_scope{ix, ix->opt_margin};
+    {   // the last stream-ordered certification's counts, if they have arrived (host-visible words, no synchronisation): a search
+        // that flagged a large share of its queries or left some unresolved switches the optimistic scans off for a while
+        const unsigned fl = ix->sticky_host[2], un = ix->sticky_host[3];
+        if (fl != 0u || un != 0u) {
+            if (un > 0u || (fl >= 64u && (int64_t)fl * 8 > ix->stats_nq)) ix->fast_skip = 8;
+            ix->sticky_host[2] = 0u;
+            ix->sticky_host[3] = 0u;
+        }
+    }
     if (!done && ix->opt_margin == 1 && out_dev && !split && ix->opt_f32_fast == 1) {
         const bool two_stage = ix->plane > 0 && ix->hp > 0 && (ix->hp <= 768 || k <= 7);
         const bool pools = ix->plane == 0 && ix->esize == 2 && k >= 8 && k <= 13 && ix->ld % 128 == 0 && ix->ld >= 384 && ix->ld <= 768;
@@ -1545,6 +1667,8 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
             rc = ensure_xmax2(ix, st); // (on the fp32 rows: before the index is viewed as rows_hi)
             if (rc) return rc;
         }
+        // (pools of 32, not 16: with the 16th best score as the bound 30 of 4096 Gaussian queries went to the second stage, and
+        // a second stage of even one query tile costs more than stage 1 saved -- 22 ms per call instead of 5.4)
         if (fast && hi_long) {
             rc = scan_and_finish<32>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, tail_st, split, true);
         } else if (k <= 5) {
@@ -1768,6 +1892,7 @@ int mips_index_set_param(mips_index_t* ix, const char* name, int64_t value) {
     else if (n == "qgroups") ix->opt_qgroups = (int)value;
     else if (n == "variant") ix->opt_variant = (int)value;
     else if (n == "tiny") ix->opt_tiny = value == 2 ? 2 : value != 0 ? 1 : 0; // 2: one launch, fall-back paths forced (tests)
+    else if (n == "resolve") ix->opt_resolve = value != 0 ? 1 : 0;
     else if (n == "f32_fast" || n == "optimistic") { // (one switch: two-stage fp32 search and optimistic pools, include/mips_hip.h)
         if (value < 0 || value > 2) return fail(MIPS_E_INVALID, "mips_index_set_param: f32_fast / optimistic must be 0, 1 or 2");
         ix->opt_f32_fast = (int)value;
