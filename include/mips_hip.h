@@ -280,18 +280,21 @@ int mips_index_check_error(mips_index_t* index, int synchronize, void* hip_strea
  *   1  (default) flag and count on the device -- nothing synchronises; read the count with this call.  Exception: where
  *      a certificate buys a faster scan (fp32-exact index; 8 <= k <= 13 on a bf16 index at row pitch 384 .. 768) device-output
  *      searches behave as in mode 3 -- still without synchronising; "f32_fast" = 0 keeps them on the plain scans;
- *   2  certify: mips_search synchronises and re-scans the flagged queries with the widest lists (K' = 32; 16 on an
- *      fp8 index), overwriting their rows.  Searches into HOST buffers synchronise anyway and always do this unless
- *      the check is off.
- *   3  certify WITHOUT synchronising (device outputs): the flag list is compacted on the device and the re-scan is
- *      enqueued behind the first scan, sized for all queries; its workgroups read the flagged count and leave when they are
- *      past it.  Costs a handful of empty launches (tens of microseconds) when nothing is flagged.  Searches in this mode
+ *   2  certify: flagged queries are settled EXACTLY -- one pass over the stored rows per 8 flagged queries computes the
+ *      canonical scores by brute force (csrc/resolve_kernels.hpp) and the rows reaching the current k-th result are ranked
+ *      over it -- and mips_search synchronises to read the counts.  Searches into HOST buffers synchronise anyway and always
+ *      do this unless the check is off.  (Rows of more than 1024 columns, searches that flag more than 256 queries, and
+ *      "resolve" = 0: re-scan of the flagged queries with the widest lists, K' = 32 / 16 on fp8, as in the first version.)
+ *   3  the same WITHOUT synchronising (device outputs): flag list and count live on the device, the passes are enqueued
+ *      behind the first scan and leave at once when nothing is flagged (tens of microseconds).  Searches in this mode
  *      also take the optimistic / two-stage paths ("f32_fast") and never the one-launch kernel; split-tail searches
- *      (mips_search_split) only count.  Host-buffer searches behave as in mode 2.
+ *      (mips_search_split) only count; more than 256 flagged queries stay unresolved (counted).  Host-buffer searches
+ *      behave as in mode 2.
  * Outputs of the LAST search on the index: flagged = queries flagged by the first pass (-1: only counted on the
- * device and synchronize == 0), rescanned = queries re-scanned, unresolved = queries still flagged afterwards (their
- * results are the best this build can do; on tie-free data they are exact in practice -- the MFMA error observed is
- * ~sqrt(d) 2^-24, two orders of magnitude below the bound).  Nothing in the reference corresponds (faiss IndexFlat
+ * device and synchronize == 0), rescanned = queries settled exactly (or re-scanned), unresolved = queries left with their
+ * first result: more than 64 rows tie with the k-th result exactly, or the search flagged more than it resolves (on tie-free
+ * data the first result is exact in practice -- the MFMA error observed is ~sqrt(d) 2^-24, two orders of magnitude below
+ * the bound).  Nothing in the reference corresponds (faiss IndexFlat
  * computes its scores in fp32 as well and offers no certificate). */
 int mips_index_margin_stats(mips_index_t* index, int64_t* flagged, int64_t* rescanned, int64_t* unresolved,
                             int synchronize, void* hip_stream);
