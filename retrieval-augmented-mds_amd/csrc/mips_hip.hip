@@ -513,12 +513,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
 #else
     const bool short_lists = false;
 #endif
-#ifdef MIPS_EXPERIMENTAL
-    const bool kll4 = want_v4 && ix->ld == 768 && (ix->opt_sub == 42 || ix->opt_sub == 43 || ix->opt_sub == 44); // sub-lists of 4 (A/B)
-#else
-    const bool kll4 = false;
-#endif
-    const size_t ncand = (size_t)nsplit * lists * (kll4 ? 4 : (want_v4 || want_v5 || want_ks || want_f8x || short_lists) ? V4_KLL : KL);
+    const size_t ncand = (size_t)nsplit * lists * ((want_v4 || want_v5 || want_ks || want_f8x || short_lists) ? V4_KLL : KL);
     int rc = ix->part_s.ensure((size_t)nq_pad * ncand * sizeof(float));
     if (rc) return rc;
     rc = ix->part_i.ensure((size_t)nq_pad * ncand * sizeof(int));
@@ -599,11 +594,6 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             const bool nt = nqt == 1 && ix->opt_sub != 30; // one query tile: every document block has a single reader
 #ifdef MIPS_EXPERIMENTAL
             if (ix->ld == 768 && ix->opt_sub == 8) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 1>); // timing only: no epilogue
-            else if (ix->ld == 768 && ix->opt_sub == 40) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 0, false, 1, true>); // next block's poll + first fragments before the epilogue
-            else if (ix->ld == 768 && ix->opt_sub == 41) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 3, 0, false, 1, true>); // the same, prefetch depth 3
-            else if (ix->ld == 768 && ix->opt_sub == 42) rc2 = go4(mips::scan_kernel_v4<4, 24, 2, 0, false, 1, true>);      // sub-lists of 4 + PIPE
-            else if (ix->ld == 768 && ix->opt_sub == 43) rc2 = go4(mips::scan_kernel_v4<4, 24, 2, 0, false, 1, false>);     // sub-lists of 4 alone
-            else if (ix->ld == 768 && ix->opt_sub == 44) rc2 = go4(mips::scan_kernel_v4<4, 24, 3, 0, false, 1, true>);      // sub-lists of 4 + PIPE, depth 3
             else
 #endif
             if (v4_opt) { // pools of 16 / 32: every sub-list vouches for its 4th best (8 x 4 = 32 documents above the bound)
@@ -758,7 +748,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     m.out_packed = d_out_packed;
     m.err = a.err;
     m.sticky = ix->sticky_dev;
-    m.ll = kll4 ? 4 : (want_v4 || want_v5 || want_ks || want_f8x || short_lists) ? V4_KLL : KL;
+    m.ll = (want_v4 || want_v5 || want_ks || want_f8x || short_lists) ? V4_KLL : KL;
     m.pre_bnd = nullptr;
     m.npre = 0;
     m.bnd = nullptr;

@@ -44,10 +44,7 @@ __device__ __forceinline__ unsigned lane_id_here() {
 }
 
 // NT_DOCS: non-temporal document DMA -- for searches of ONE query tile, where every document block has a single reader
-// PIPE: the arrival poll of block i + 1 and the loads of its first AD fragments are issued at the END of block i, in front of
-// block i's second-half epilogue, instead of at the top of block i + 1 in front of its first MFMA (all eight waves pass the
-// block barrier together, so the SIMD partner cannot cover that LDS round trip)
-template <int KL, int KS32, int AD, int TIMING_MODE = 0, bool NT_DOCS = false, int PUB = 1, bool PIPE = false>
+template <int KL, int KS32, int AD, int TIMING_MODE = 0, bool NT_DOCS = false, int PUB = 1>
 __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WAVES = 8;
@@ -211,13 +208,11 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
         }
     };
 
-    bf16x8 ar_next[PIPE ? AD : 1]; // PIPE: the first AD fragments of the block about to start
-    auto block = [&](bool refresh, int blk, int stage, const unsigned char* pbase, int pstage, int nstage, bool has_next) {
+    auto block = [&](bool refresh, int blk, int stage, const unsigned char* pbase, int pstage) {
         if (idle_wave) { // all of this wave's queries are padding (scan_kernel_v3.hpp): bring the documents, skip the arithmetic
             refresh_thresholds(false);
             issue(pbase, pstage);
             arrive();
-            if (PIPE && has_next) wait_all();
             return;
         }
         const unsigned char* sa = smem + stage * STAGE_BYTES;
@@ -230,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
         };
         bf16x8 ar[AD];
 #pragma unroll
-        for (int t = 0; t < AD; ++t) ar[t] = PIPE ? ar_next[PIPE ? t : 0] : lds_frag(t);
+        for (int t = 0; t < AD; ++t) ar[t] = lds_frag(t);
         refresh_thresholds(refresh); // first VMEM op of the block
         __builtin_amdgcn_sched_barrier(0);
         const bool ragged = (int64_t)(blk + 1) * V3_DB > p.ntotal; // uniform
@@ -251,15 +246,6 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (half == 1) arrive(); // all LDS reads of this block are done; the epilogue runs un-synchronised
-            if (PIPE && half == 1 && has_next) { // next block: everyone has arrived -> its first fragments travel under the epilogue below
-                wait_all();
-                const unsigned char* sn = smem + nstage * STAGE_BYTES;
-#pragma unroll
-                for (int t = 0; t < AD; ++t) {
-                    const int s = t % KS32;
-                    ar_next[PIPE ? t : 0] = *reinterpret_cast<const bf16x8*>(sn + (t / KS32) * 2048 + (s >> 1) * 4096 + ((s & 1) ? (rd0 ^ 64) : rd0));
-                }
-            }
             if (half == 1 && refresh && TIMING_MODE == 0) {
                 // minimum of the 8 class words of queries c and 16 + c (what an earlier block's DMA brought, or 0);
                 // inline asm, one query at a time: see scan_kernel_v3.hpp
@@ -309,20 +295,9 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
     if (tid == 0) *reinterpret_cast<unsigned*>(smem + DUMP_AREA + 1024) = 0u;
     __syncthreads();
     if (nb > 0) arrive();
-    if (PIPE && nb > 0) {
-        wait_all();
-        if (!idle_wave) {
-            const int rd0 = rd0_of(lane_id_here());
-#pragma unroll
-            for (int t = 0; t < AD; ++t) {
-                const int s = t % KS32;
-                ar_next[PIPE ? t : 0] = *reinterpret_cast<const bf16x8*>(smem + (t / KS32) * 2048 + (s >> 1) * 4096 + ((s & 1) ? (rd0 ^ 64) : rd0));
-            }
-        }
-    }
     for (int i = 0; i < nb; ++i) {
-        if (!PIPE) wait_all();
-        block(i < 8 || (i & 7) == 0, b0 + i, stage, pbase, pstage, stage == STAGES - 1 ? 0 : stage + 1, i + 1 < nb); // refresh schedule: scan_kernel_v3.hpp
+        wait_all();
+        block(i < 8 || (i & 7) == 0, b0 + i, stage, pbase, pstage); // refresh schedule: scan_kernel_v3.hpp
         if (i + AHEAD + 1 < nb) pbase += blk_bytes;
         stage = stage == STAGES - 1 ? 0 : stage + 1;
         pstage = pstage == STAGES - 1 ? 0 : pstage + 1;
