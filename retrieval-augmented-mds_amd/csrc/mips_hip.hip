@@ -987,12 +987,13 @@ int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
     a.out_i = d_i;
     a.out_packed = packed ? d_i : nullptr;
     a.unresolved = unres;
-    const int lds = mips::RESOLVE_QB * a.ld * (int)sizeof(double) + 4 * 64 * 9 * 16;
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (ix->ntotal + 255) / 256));
+    const int lds = mips::RESOLVE_QB * a.ld * (int)sizeof(double) + mips::RESOLVE_WAVES * 64 * 9 * 16;
+    const int rows_per_wg = 64 * mips::RESOLVE_WAVES;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (ix->ntotal + rows_per_wg - 1) / rows_per_wg));
     const bool l2 = ix->call_metric == MIPS_METRIC_L2;
     auto go = [&](auto kern) -> int {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        kern<<<grid, 256, lds, st>>>(a);
+        kern<<<grid, 64 * mips::RESOLVE_WAVES, lds, st>>>(a);
         return MIPS_OK;
     };
     if (f32x) rc = l2 ? go(mips::exact_filter_kernel<mips::ElemF32, true>) : go(mips::exact_filter_kernel<mips::ElemF32, false>);

@@ -26,6 +26,7 @@
 namespace mips {
 
 constexpr int RESOLVE_QB = 8;     // flagged queries per pass over the index
+constexpr int RESOLVE_WAVES = 8;  // per workgroup
 constexpr int RESOLVE_CAP = 64;   // hits kept per query
 constexpr int RESOLVE_MAX = 256;  // flagged queries resolved per search = 32 passes over the index; a search that flags more is
                                   // served by the tile re-scan when it may synchronise, left unresolved (counted) when it may not
@@ -57,16 +58,17 @@ __device__ __forceinline__ float resolve_key(double dot, double qq, double phi) 
     return L2 ? -(float)(qq + phi - 2.0 * dot) : (float)dot;
 }
 
-// 256 threads = 4 waves; wave w of workgroup b owns rows (b * 4 + w) * 64 .. + 63 of each grid stride
+// RESOLVE_WAVES waves; wave w of workgroup b owns rows (b * RESOLVE_WAVES + w) * 64 .. + 63 of each grid stride
+// (8 waves = two per SIMD: one wave alone cannot cover the LDS round trips between its fp64 chains)
 template <typename EL, bool L2>
-__global__ __launch_bounds__(256) void exact_filter_kernel(ResolveArgs a) {
+__global__ __launch_bounds__(64 * RESOLVE_WAVES) void exact_filter_kernel(ResolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n = *a.n_dev;
     if (n == 0 || n > RESOLVE_MAX) return;
     constexpr int PER = EL::PER16;               // elements per 16-byte chunk
     constexpr int TCH = 8;                       // chunks per row per tile step: 128 bytes
     double* yd = reinterpret_cast<double*>(smem);                                   // [RESOLVE_QB][ld] queries of the batch, fp64
-    unsigned char* tiles = smem + (size_t)RESOLVE_QB * a.ld * sizeof(double);       // [4 waves][64 rows][TCH + 1 chunks]
+    unsigned char* tiles = smem + (size_t)RESOLVE_QB * a.ld * sizeof(double);       // [waves][64 rows][TCH + 1 chunks]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32x4* tile = reinterpret_cast<u32x4*>(tiles) + wave * 64 * (TCH + 1);
     const int nchunk = a.ld / PER;               // 16-byte chunks per row, a multiple of TCH
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void exact_filter_kernel(ResolveArgs a) {
     for (int j0 = 0; j0 < n; j0 += RESOLVE_QB) {
         __syncthreads(); // (the previous batch's queries are no longer read)
         // the batch's queries -> fp64 in LDS (rows past n: zeros)
-        for (int t = tid; t < RESOLVE_QB * nchunk; t += 256) {
+        for (int t = tid; t < RESOLVE_QB * nchunk; t += 64 * RESOLVE_WAVES) {
             const int j = t / nchunk, c = t % nchunk;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (j0 + j < n) v = *reinterpret_cast<const u32x4*>(ys + (size_t)a.ids[j0 + j] * a.ld + (size_t)c * PER);
@@ -92,22 +94,30 @@ __global__ __launch_bounds__(256) void exact_filter_kernel(ResolveArgs a) {
             kk[j] = qid >= 0 ? a.keyk[qid] : INFINITY;
             qn[j] = qid >= 0 && L2 ? a.qq[qid] : 0.0;
         }
-        for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 64; r0 < a.ntotal; r0 += (int64_t)gridDim.x * 256) {
+        for (int64_t r0 = ((int64_t)blockIdx.x * RESOLVE_WAVES + wave) * 64; r0 < a.ntotal; r0 += (int64_t)gridDim.x * 64 * RESOLVE_WAVES) {
             const int64_t row = r0 + lane;
             double acc[RESOLVE_QB];
 #pragma unroll
             for (int j = 0; j < RESOLVE_QB; ++j) acc[j] = 0.0;
-            for (int c0 = 0; c0 < nchunk; c0 += TCH) {
-                // coalesced: 8 lanes cover the 128-byte segment of one row, 8 rows per load instruction
-                u32x4 in[8];
+            // coalesced: 8 lanes cover the 128-byte segment of one row, 8 rows per load instruction; the NEXT segment's loads
+            // are in flight while this one is summed (4 waves per CU: nothing else hides the memory round trip)
+            const typename EL::type* src[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    int64_t rr = r0 + 8 * i + (lane >> 3);
-                    if (rr >= a.ntotal) rr = a.ntotal - 1; // (clamped: the lane's own row test drops it below)
-                    in[i] = *reinterpret_cast<const u32x4*>(rows + (size_t)rr * a.ld + (size_t)(c0 + (lane & 7)) * PER);
-                }
+            for (int i = 0; i < 8; ++i) {
+                int64_t rr = r0 + 8 * i + (lane >> 3);
+                if (rr >= a.ntotal) rr = a.ntotal - 1; // (clamped: the lane's own row test drops it below)
+                src[i] = rows + (size_t)rr * a.ld + (size_t)(lane & 7) * PER;
+            }
+            u32x4 in[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) in[i] = *reinterpret_cast<const u32x4*>(src[i]);
+            for (int c0 = 0; c0 < nchunk; c0 += TCH) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) tile[(8 * i + (lane >> 3)) * (TCH + 1) + (lane & 7)] = in[i];
+                if (c0 + TCH < nchunk) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) in[i] = *reinterpret_cast<const u32x4*>(src[i] + (size_t)(c0 + TCH) * PER);
+                }
                 __builtin_amdgcn_wave_barrier(); // (one wave: LDS operations complete in order)
 #pragma unroll
                 for (int c = 0; c < TCH; ++c) {
