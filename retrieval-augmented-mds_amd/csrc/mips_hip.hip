@@ -1604,7 +1604,7 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
         if (two_stage || pools) {
             if (ix->fast_skip > 0) --ix->fast_skip; // (a recent call flagged too much for the fast scan to pay: plain mode 1)
             else ix->opt_margin = 3;
-        } else if ((double)nq * (double)ix->ntotal * (double)ix->ld >= 1.5e15 && (ix->plane > 0 ? ix->plane : ix->ld) <= 1024) {
+        } else if ((double)nq * (double)ix->ntotal * (double)ix->ld >= 1.5e12 && (ix->plane > 0 ? ix->plane : ix->ld) <= 1024) {
             // a scan of milliseconds (half of BASELINE config 2 and up): the handful of launches of the stream-ordered
             // certificate -- tens of microseconds when nothing is flagged -- is below 1 % of it, so large searches are
             // exact without a caveat by default
