@@ -898,9 +898,13 @@ __global__ void scatter_f32_kernel(const float* src, const int* ids, int64_t n, 
 }
 
 // flagged queries -> ascending list of their numbers + count (one workgroup; stream-ordered re-scan)
-__global__ __launch_bounds__(256) void compact_flags_kernel(const unsigned char* flags, int nq, int* ids, int* count) {
+// zero / nzero: words the same launch clears for what follows (hit counters and the unresolved counter of the exact pass)
+__global__ __launch_bounds__(256) void compact_flags_kernel(const unsigned char* flags, int nq, int* ids, int* count, int* zero = nullptr,
+                                                            int nzero = 0, unsigned* zero2 = nullptr) {
     __shared__ int part[256];
     const int t = threadIdx.x;
+    for (int z = t; z < nzero; z += 256) zero[z] = 0;
+    if (t == 0 && zero2 != nullptr) *zero2 = 0u;
     const int per = (nq + 255) / 256;
     const int lo = t * per, hi = lo + per < nq ? lo + per : nq;
     int c = 0;

@@ -941,7 +941,8 @@ int tiny_search(mips_index* ix, const void* q_dev, int q_dtype, int64_t nq, int 
 // flagged more than RESOLVE_MAX queries is handed to the tile re-scan (return value kUseRescan).  Otherwise everything is
 // enqueued blind; the counts travel to host-visible words for the next search to look at (mips_index::stats_host).
 constexpr int kUseRescan = 1;
-int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, bool packed, int64_t idx_offset, hipStream_t st, bool certify_now) {
+int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, bool packed, int64_t idx_offset, hipStream_t st, bool certify_now,
+                    bool first_was_optimistic) {
     int rc = ix->ids.ensure((size_t)(nq + 4) * sizeof(int));
     if (rc) return rc;
     int* ids = (int*)ix->ids.p;
@@ -954,8 +955,7 @@ int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
     rc = ix->hit_n.ensure((size_t)mips::RESOLVE_MAX * sizeof(int));
     if (rc) return rc;
     if (!ix->nflag_host) HIP_TRY(hipHostMalloc((void**)&ix->nflag_host, 64, hipHostMallocDefault));
-    mips::compact_flags_kernel<<<1, 256, 0, st>>>((const unsigned char*)ix->mflag.p, (int)nq, ids, cnt);
-    HIP_TRY(hipMemsetAsync(unres, 0, sizeof(unsigned), st));
+    mips::compact_flags_kernel<<<1, 256, 0, st>>>((const unsigned char*)ix->mflag.p, (int)nq, ids, cnt, (int*)ix->hit_n.p, mips::RESOLVE_MAX, unres);
     if (certify_now) {
         HIP_TRY(hipMemcpyAsync(&ix->nflag_host[0], cnt, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -966,7 +966,6 @@ int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
         if (n == 0) return MIPS_OK;
         if (n > mips::RESOLVE_MAX) return kUseRescan;
     }
-    HIP_TRY(hipMemsetAsync(ix->hit_n.p, 0, (size_t)mips::RESOLVE_MAX * sizeof(int), st));
     mips::ResolveArgs a;
     const bool f32x = ix->plane > 0;
     a.rows = f32x ? (const void*)ix->rows_f32 : (const void*)ix->rows;
@@ -1013,9 +1012,11 @@ int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
         ix->last_unresolved = (int64_t)ix->nflag_host[1];
     } else {
         ix->last_flagged = -1;
-        ix->stats_nq = nq;
-        mips::publish_resolve_stats_kernel<<<1, 1, 0, st>>>(cnt, unres, ix->sticky_dev + 2);
-        HIP_TRY(hipGetLastError());
+        if (first_was_optimistic) { // (only the optimistic scans are steered by what the last search flagged)
+            ix->stats_nq = nq;
+            mips::publish_resolve_stats_kernel<<<1, 1, 0, st>>>(cnt, unres, ix->sticky_dev + 2);
+            HIP_TRY(hipGetLastError());
+        }
     }
     return MIPS_OK;
 }
@@ -1105,7 +1106,7 @@ int finish_margin(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, b
     // flagged queries are settled exactly, by brute force on the canonical scores (rows of up to 1024 columns; beyond that
     // -- and with "resolve" = 0 -- by the re-scan with the widest lists below)
     if (ix->opt_resolve != 0 && (ix->plane > 0 ? ix->plane : ix->ld) <= 1024) {
-        const int r = resolve_flagged(ix, nq, k, d_s, d_i, packed, idx_offset, st, !(out_dev && ix->opt_margin == 3));
+        const int r = resolve_flagged(ix, nq, k, d_s, d_i, packed, idx_offset, st, !(out_dev && ix->opt_margin == 3), fast_first);
         if (r != kUseRescan) return r;
         ix->first_nflag_dev = nullptr; // (more flagged than the exact pass takes: the tile re-scan below, which synchronises)
     } else if (out_dev && ix->opt_margin == 3) {
