@@ -468,9 +468,11 @@ def main():
                        "rows_per_gpu": rows_per_gpu if world > 1 else local_rows},
             "distributed": dist_info,
             "step_ms": step_stats,
-            "margin_check": {"flagged_queries_last_step": margin["flagged"], "of": nq, "mode": "certified on the stream: searches of this size settle the queries "
-                             "they flag exactly (brute force on the canonical scores, one pass over the index per 8 flagged queries), without "
-                             "synchronising; small device-output searches (nq x rows x d < 1.5e12, k <= 7) only count",
+            "margin_check": {"flagged_queries_last_step": margin["flagged"], "of": nq,
+                             "mode": ("count only: the pipelined steps (scan and tail on two streams) and searches below nq x rows x d = 1.5e12 "
+                                      "per GPU do not run the certificate") if (pipelined or float(nq) * local_rows * d < 1.5e12) else
+                                     ("certified on the stream: searches of this size settle the queries they flag exactly (brute force on the "
+                                      "canonical scores, one pass over the index per 8 flagged queries), without synchronising"),
                              "bound": "exact k-th score within d*2^-23*|q|*max|x| of the best MFMA score outside the candidate pool"},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_torch": cpu_t, "parity_vs_cpu_sample": parity,
             "regimes": regimes,
