@@ -469,8 +469,8 @@ def main():
             "distributed": dist_info,
             "step_ms": step_stats,
             "margin_check": {"flagged_queries_last_step": margin["flagged"], "of": nq,
-                             "mode": ("count only: the pipelined steps (scan and tail on two streams) and searches below nq x rows x d = 1.5e12 "
-                                      "per GPU do not run the certificate") if (pipelined or float(nq) * local_rows * d < 1.5e12) else
+                             "mode": ("count only: searches below nq x rows x d = 1.5e12 per GPU do not run the certificate")
+                                     if float(nq) * local_rows * d < 1.5e12 else
                                      ("certified on the stream: searches of this size settle the queries they flag exactly (brute force on the "
                                       "canonical scores, one pass over the index per 8 flagged queries), without synchronising"),
                              "bound": "exact k-th score within d*2^-23*|q|*max|x| of the best MFMA score outside the candidate pool"},

@@ -290,7 +290,7 @@ int mips_index_check_error(mips_index_t* index, int synchronize, void* hip_strea
  *   3  the same WITHOUT synchronising (device outputs): flag list and count live on the device, the passes are enqueued
  *      behind the first scan and leave at once when nothing is flagged (tens of microseconds).  Searches in this mode
  *      also take the optimistic / two-stage paths ("f32_fast") and never the one-launch kernel; split-tail searches
- *      (mips_search_split) only count; more than 256 flagged queries stay unresolved (counted).  Host-buffer searches
+ *      (mips_search_split) run the passes on their tail stream; more than 256 flagged queries stay unresolved (counted).  Host-buffer searches
  *      behave as in mode 2.
  * Outputs of the LAST search on the index: flagged = queries flagged by the first pass (-1: only counted on the
  * device and synchronize == 0), rescanned = queries settled exactly (or re-scanned), unresolved = queries left with their

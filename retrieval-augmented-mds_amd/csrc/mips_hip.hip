@@ -1225,8 +1225,15 @@ int scan_and_finish(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
     const bool first_was_optimistic = ix->optimistic;
     ix->optimistic = false;
     if (rc) return rc;
-    if (split) {
-        ix->last_flagged = -1; // counted on the device only
+    if (split) { // scan on st, tail on tail_st: the certificate, when asked for, is part of the tail
+        ix->last_flagged = -1;
+        ix->first_nflag_dev = nullptr;
+        if (ix->opt_margin == 3 && out_dev && ix->opt_resolve != 0 && (ix->plane > 0 ? ix->plane : ix->ld) <= 1024) {
+            rc = resolve_flagged(ix, nq, k, d_s, d_i, packed, idx_offset, tail_st, false, false);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ix->tail_done[ix->cur_set], tail_st)); // (supersedes the record behind the re-score: the exact
+            ix->tail_pending[ix->cur_set] = true;                         // pass reads this set's staged queries)
+        }
         return MIPS_OK;
     }
     rc = finish_margin<KL>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, first_was_optimistic);
@@ -1599,16 +1606,16 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
             ix->sticky_host[3] = 0u;
         }
     }
-    if (!done && ix->opt_margin == 1 && out_dev && !split && ix->opt_f32_fast == 1) {
-        const bool two_stage = ix->plane > 0 && ix->hp > 0 && (ix->hp <= 768 || k <= 7);
-        const bool pools = ix->plane == 0 && ix->esize == 2 && k >= 8 && k <= 13 && ix->ld % 128 == 0 && ix->ld >= 384 && ix->ld <= 768;
+    if (!done && ix->opt_margin == 1 && out_dev && ix->opt_f32_fast == 1) {
+        const bool two_stage = !split && ix->plane > 0 && ix->hp > 0 && (ix->hp <= 768 || k <= 7);
+        const bool pools = !split && ix->plane == 0 && ix->esize == 2 && k >= 8 && k <= 13 && ix->ld % 128 == 0 && ix->ld >= 384 && ix->ld <= 768;
         if (two_stage || pools) {
             if (ix->fast_skip > 0) --ix->fast_skip; // (a recent call flagged too much for the fast scan to pay: plain mode 1)
             else ix->opt_margin = 3;
         } else if ((double)nq * (double)ix->ntotal * (double)ix->ld >= 1.5e12 && (ix->plane > 0 ? ix->plane : ix->ld) <= 1024) {
             // a scan of milliseconds (half of BASELINE config 2 and up): the handful of launches of the stream-ordered
             // certificate -- tens of microseconds when nothing is flagged -- is below 1 % of it, so large searches are
-            // exact without a caveat by default
+            // exact without a caveat by default (split-tail searches: on the tail stream)
             ix->opt_margin = 3;
         }
     }

@@ -1506,6 +1506,14 @@ def test_near_duplicates_crowding_one_sub_list_are_certified(nq):
     assert np.array_equal(di.cpu().numpy()[free], fi) and np.array_equal(ds.cpu().numpy()[free], fs)
     pk = ix.search_packed(qd, k, 500)
     assert np.array_equal(pk[..., 1].cpu().numpy()[stars], ei + 500) and np.array_equal(pk[..., 1].cpu().numpy()[free], fi + 500)
+    # split-tail searches (scan on the current stream, select + re-score + the certificate on another): three in flight
+    tail = torch.cuda.Stream()
+    outs = [ix.search(qd, k, tail_stream=tail) for _ in range(3)]
+    torch.cuda.synchronize()
+    for ts, ti in outs:
+        assert np.array_equal(ti.cpu().numpy()[stars], ei) and np.array_equal(ts.cpu().numpy()[stars], es)
+        assert np.array_equal(ti.cpu().numpy()[free], fi) and np.array_equal(ts.cpu().numpy()[free], fs)
+    assert ix.margin_stats() == st
     g = torch.cuda.CUDAGraph()
     buf = qd.clone()
     side = torch.cuda.Stream()
