@@ -285,12 +285,12 @@ int mips_index_check_error(mips_index_t* index, int synchronize, void* hip_strea
  *   2  certify: flagged queries are settled EXACTLY -- one pass over the stored rows per 8 flagged queries computes the
  *      canonical scores by brute force (csrc/resolve_kernels.hpp) and the rows reaching the current k-th result are ranked
  *      over it -- and mips_search synchronises to read the counts.  Searches into HOST buffers synchronise anyway and always
- *      do this unless the check is off.  (Rows of more than 1024 columns, searches that flag more than 256 queries, and
+ *      do this unless the check is off.  (Rows of more than 1024 columns, searches that flag more than 1024 queries, and
  *      "resolve" = 0: re-scan of the flagged queries with the widest lists, K' = 32 / 16 on fp8, as in the first version.)
  *   3  the same WITHOUT synchronising (device outputs): flag list and count live on the device, the passes are enqueued
  *      behind the first scan and leave at once when nothing is flagged (tens of microseconds).  Searches in this mode
  *      also take the optimistic / two-stage paths ("f32_fast") and never the one-launch kernel; split-tail searches
- *      (mips_search_split) run the passes on their tail stream; more than 256 flagged queries stay unresolved (counted).  Host-buffer searches
+ *      (mips_search_split) run the passes on their tail stream; more than 1024 flagged queries stay unresolved (counted).  Host-buffer searches
  *      behave as in mode 2.
  * Outputs of the LAST search on the index: flagged = queries flagged by the first pass (-1: only counted on the
  * device and synchronize == 0), rescanned = queries settled exactly (or re-scanned), unresolved = queries left with their

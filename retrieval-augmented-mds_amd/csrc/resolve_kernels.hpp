@@ -28,8 +28,9 @@ namespace mips {
 constexpr int RESOLVE_QB = 8;     // flagged queries per pass over the index
 constexpr int RESOLVE_WAVES = 8;  // per workgroup
 constexpr int RESOLVE_CAP = 64;   // hits kept per query
-constexpr int RESOLVE_MAX = 256;  // flagged queries resolved per search = 32 passes over the index; a search that flags more is
-                                  // served by the tile re-scan when it may synchronise, left unresolved (counted) when it may not
+constexpr int RESOLVE_MAX = 1024; // flagged queries resolved per search = 128 passes over the index (the tile re-scan costs more per
+                                  // query even then); a search that flags more is served by the tile re-scan when it may
+                                  // synchronise, left unresolved (counted) when it may not
 
 struct ResolveArgs {
     const void* rows;     // stored rows the canonical score is defined on (bf16 / e4m3 index rows, fp32 rows of the fp32-exact index)

@@ -1477,7 +1477,7 @@ def test_near_duplicates_crowding_one_sub_list_are_certified(nq):
     assert np.array_equal(i[free], fi) and np.array_equal(s[free], fs)
     assert st["flagged"] >= len(stars) and st["rescanned"] == st["flagged"] and st["unresolved"] == 0, st
     # the older way to settle flagged queries -- re-scan with the widest lists instead of the exact brute-force pass -- still
-    # serves rows of more than 1024 columns and searches that flag more than 256 queries; same answer here
+    # serves rows of more than 1024 columns and searches that flag more than 1024 queries; same answer here
     ix.set_param("resolve", 0)
     s0, i0 = ix.search(q, k)
     assert np.array_equal(i0, i) and np.array_equal(s0, s) and ix.margin_stats()["rescanned"] == st["flagged"]
