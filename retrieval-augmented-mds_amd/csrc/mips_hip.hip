@@ -628,11 +628,16 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             if (ix->ld == 768 && ix->opt_sub == 8) rc2 = gox(mips::scan_kernel_f8x<V4_KLL, 768, 2, 1>); // timing only: no epilogue
             else
 #endif
+            if (nqt == 1) { // one query tile: non-temporal document DMA
+                if (ix->ld == 768) rc2 = gox(mips::scan_kernel_f8x<V4_KLL, 768, 2, 0, true>);
+                else if (ix->ld == 512) rc2 = gox(mips::scan_kernel_f8x<V4_KLL, 512, 2, 0, true>);
+                else rc2 = gox(mips::scan_kernel_f8x<V4_KLL, 256, 2, 0, true>);
+            } else
             if (ix->ld == 768) rc2 = gox(mips::scan_kernel_f8x<V4_KLL, 768, 2>);
             else if (ix->ld == 512) rc2 = gox(mips::scan_kernel_f8x<V4_KLL, 512, 2>);
             else rc2 = gox(mips::scan_kernel_f8x<V4_KLL, 256, 2>);
             if (rc2) return rc2;
-            set_kernel_name(ix, "mips::scan_kernel_f8x<%d, %d, 2, 0>", V4_KLL, ix->ld);
+            set_kernel_name(ix, nqt == 1 ? "mips::scan_kernel_f8x<%d, %d, 2, 0, true>" : "mips::scan_kernel_f8x<%d, %d, 2, 0, false>", V4_KLL, ix->ld);
         }
     } else if (f8) {
         if constexpr (KL <= 16) {
@@ -648,12 +653,18 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
                 return MIPS_OK;
             };
             int rc2;
+            if (nqt == 1) { // one query tile: non-temporal document DMA
+                if (ix->ld == 1024) rc2 = gof8(mips::scan_kernel_f8<KL, 1024, 2, true>);
+                else if (ix->ld == 768) rc2 = gof8(mips::scan_kernel_f8<KL, 768, 2, true>);
+                else if (ix->ld == 512) rc2 = gof8(mips::scan_kernel_f8<KL, 512, 2, true>);
+                else rc2 = gof8(mips::scan_kernel_f8<KL, 256, 2, true>);
+            } else
             if (ix->ld == 1024) rc2 = gof8(mips::scan_kernel_f8<KL, 1024, 2>);
             else if (ix->ld == 768) rc2 = gof8(mips::scan_kernel_f8<KL, 768, 2>);
             else if (ix->ld == 512) rc2 = gof8(mips::scan_kernel_f8<KL, 512, 2>);
             else rc2 = gof8(mips::scan_kernel_f8<KL, 256, 2>);
             if (rc2) return rc2;
-            set_kernel_name(ix, "mips::scan_kernel_f8<%d, %d, 2>", KL, ix->ld);
+            set_kernel_name(ix, nqt == 1 ? "mips::scan_kernel_f8<%d, %d, 2, true>" : "mips::scan_kernel_f8<%d, %d, 2, false>", KL, ix->ld);
         }
     } else if (variant == 1) {
         HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel<KL>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -31,7 +31,8 @@ struct ScanArgsF8 {
     ScanArgs c;          // common fields (docs/qbuf in there are unused)
 };
 
-template <int KL, int LD, int AD>
+// NT_DOCS: non-temporal document DMA for searches of ONE query tile (every block has a single reader), as in scan_kernel_v3 / v4
+template <int KL, int LD, int AD, bool NT_DOCS = false>
 __global__ __launch_bounds__(512, 2) void scan_kernel_f8(ScanArgsF8 pa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ScanArgs& p = pa.c;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_f8(ScanArgsF8 pa) {
         const int pc = wave + WAVES * i;
         const int slab = pc >> 2, rg = pc & 3;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + stage * STAGE_BYTES + pc * 1024), 16,
-                                                 (rg & 1) ? (lane_off0 ^ 64u) : lane_off0, rg * 8 * LD + slab * 128, 0, 0);
+                                                 (rg & 1) ? (lane_off0 ^ 64u) : lane_off0, rg * 8 * LD + slab * 128, 0, NT_DOCS ? 2 : 0);
     };
     auto issue = [&](const unsigned char* blk_base, int stage) {
 #pragma unroll

@@ -32,7 +32,8 @@ namespace mips {
 
 constexpr int F8X_DB = 64; // documents per block
 
-template <int KL, int LD, int AD, int TIMING_MODE = 0>
+// NT_DOCS: non-temporal document DMA for searches of ONE query tile (every block has a single reader)
+template <int KL, int LD, int AD, int TIMING_MODE = 0, bool NT_DOCS = false>
 __global__ __launch_bounds__(512, 2) void scan_kernel_f8x(ScanArgsF8 pa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ScanArgs& p = pa.c;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_f8x(ScanArgsF8 pa) {
         const int pc = wave + WAVES * i;
         const int slab = pc >> 3, rg = pc & 7;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + stage * STAGE_BYTES + pc * 1024), 16,
-                                                 (rg & 1) ? (lane_off0 ^ 64u) : lane_off0, rg * 8 * LD + slab * 128, 0, 0);
+                                                 (rg & 1) ? (lane_off0 ^ 64u) : lane_off0, rg * 8 * LD + slab * 128, 0, NT_DOCS ? 2 : 0);
     };
     auto issue = [&](const unsigned char* blk_base, int stage) {
 #pragma unroll
