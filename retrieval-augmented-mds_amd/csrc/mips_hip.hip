@@ -719,6 +719,9 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         if (launched) set_kernel_name(ix, "mips::scan_kernel_v3 experimental instance sub=%d", sub);
 #endif
         if (launched) {
+        } else if (ix->ld == 1024 && nqt == 1) { // one query tile: non-temporal document DMA (as at pitch 768 below)
+            rc2 = go(mips::scan_kernel_v3<KL, 64, 1, 4, false, 0, 2, 4, 2, true, true>, 256);
+            set_kernel_name(ix, "mips::scan_kernel_v3<%d, 64, 1, 4, false, 0, 2, 4, 2, true, true, 8>", KL);
         } else if (ix->ld == 1024) {
             rc2 = go(mips::scan_kernel_v3<KL, 64, 1, 4, false, 0, 2, 4, 2>, 256);
             set_kernel_name(ix, "mips::scan_kernel_v3<%d, 64, 1, 4, false, 0, 2, 4, 2, true, false, 8>", KL);
