@@ -682,11 +682,16 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             return MIPS_OK;
         };
         int rc2;
+        if (nqt == 1) { // one query tile: non-temporal document DMA
+            if (ix->ld == 768) rc2 = go4(mips::scan_kernel_v3<KL, 48, 1, 4, true, 0, 2, 4, 3, true, true>);
+            else if (ix->ld == 512) rc2 = go4(mips::scan_kernel_v3<KL, 32, 1, 4, true, 0, 2, 4, 3, true, true>);
+            else rc2 = go4(mips::scan_kernel_v3<KL, 16, 1, 4, true, 0, 2, 4, 3, true, true>);
+        } else
         if (ix->ld == 768) rc2 = go4(mips::scan_kernel_v3<KL, 48, 1, 4, true, 0, 2, 4, 3>);
         else if (ix->ld == 512) rc2 = go4(mips::scan_kernel_v3<KL, 32, 1, 4, true, 0, 2, 4, 3>);
         else rc2 = go4(mips::scan_kernel_v3<KL, 16, 1, 4, true, 0, 2, 4, 3>);
         if (rc2) return rc2;
-        set_kernel_name(ix, "mips::scan_kernel_v3<%d, %d, 1, 4, true, 0, 2, 4, 3, true, false, 8>", KL, ix->ld / 16);
+        set_kernel_name(ix, nqt == 1 ? "mips::scan_kernel_v3<%d, %d, 1, 4, true, 0, 2, 4, 3, true, true, 8>" : "mips::scan_kernel_v3<%d, %d, 1, 4, true, 0, 2, 4, 3, true, false, 8>", KL, ix->ld / 16);
     } else {
         const int lds = (v3_waves == 4 ? 2 : 3) * mips::V3_DB * ix->ld * 2 + v3_waves * 1024 + 1024 + 16; // ring + threshold words + dump area + arrival counter
         auto go = [&](auto kern, int threads) -> int {
