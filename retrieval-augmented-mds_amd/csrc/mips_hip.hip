@@ -736,7 +736,14 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, 2, 8, 3, true, true>, 512);
             set_kernel_name(ix, "mips::scan_kernel_v3<%d, 48, 1, 2, true, 0, 2, 8, 3, true, true, 8>", KL);
         } else if (ix->ld == 768) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true>, 512);
-        else if (ix->ld == 640) rc2 = go(mips::scan_kernel_v3<KL, 40, 1, 2, true>, 512);
+        else if (nqt == 1) { // one query tile at the other pitches: non-temporal document DMA as well
+            if (ix->ld == 640) rc2 = go(mips::scan_kernel_v3<KL, 40, 1, 2, true, 0, 2, 8, 3, true, true>, 512);
+            else if (ix->ld == 512) rc2 = go(mips::scan_kernel_v3<KL, 32, 1, 2, true, 0, 2, 8, 3, true, true>, 512);
+            else if (ix->ld == 384) rc2 = go(mips::scan_kernel_v3<KL, 24, 1, 2, true, 0, 2, 8, 3, true, true>, 512);
+            else if (ix->ld == 256) rc2 = go(mips::scan_kernel_v3<KL, 16, 1, 2, true, 0, 2, 8, 3, true, true>, 512);
+            else rc2 = go(mips::scan_kernel_v3<KL, 8, 1, 2, true, 0, 2, 8, 3, true, true>, 512);
+            set_kernel_name(ix, "mips::scan_kernel_v3<%d, %d, 1, 2, true, 0, 2, 8, 3, true, true, 8>", KL, ix->ld / 16);
+        } else if (ix->ld == 640) rc2 = go(mips::scan_kernel_v3<KL, 40, 1, 2, true>, 512);
         else if (ix->ld == 512) rc2 = go(mips::scan_kernel_v3<KL, 32, 1, 2, true>, 512);
         else if (ix->ld == 384) rc2 = go(mips::scan_kernel_v3<KL, 24, 1, 2, true>, 512);
         else if (ix->ld == 256) rc2 = go(mips::scan_kernel_v3<KL, 16, 1, 2, true>, 512);
