@@ -94,7 +94,7 @@ const char* mips_last_error(void);
  *   MIPS_DTYPE_FP8_E4M3  1 B/element, inputs AND queries rounded to OCP e4m3 (d <= 1024, k <= 13)
  *   MIPS_DTYPE_F32       fp32-exact: results are those of an fp32 brute force on the caller's values
  *                        (bf16 hi|lo planes for the three-segment scan + the fp32 rows for the exact re-score, 8 B/element;
- *                        for d <= 1024 also bf16(x) alone at the fast kernels' row pitch, + 2 B/element: searches that
+ *                        for d <= 1024 also bf16(x) alone at the fast kernels' row pitch, + 2 B/element: for d <= 768 searches that
  *                        certify (host buffers; device outputs re-scan on the stream, see mips_index_margin_stats) scan
  *                        THAT like a bf16 index, re-score on the fp32 rows, and send only the queries whose margin -- widened by the
  *                        representation error |x - bf16 x| |q| + |bf16 x| |q - bf16 q| -- is not certified through the

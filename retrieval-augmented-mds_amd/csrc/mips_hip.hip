@@ -1633,7 +1633,7 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
         }
     }
     if (!done && ix->opt_margin == 1 && out_dev && ix->opt_f32_fast == 1) {
-        const bool two_stage = !split && ix->plane > 0 && ix->hp > 0 && (ix->hp <= 768 || k <= 7);
+        const bool two_stage = !split && ix->plane > 0 && ix->hp > 0 && ix->hp <= 768;
         const bool pools = !split && ix->plane == 0 && ix->esize == 2 && k >= 8 && k <= 13 && ix->ld % 128 == 0 && ix->ld >= 384 && ix->ld <= 768;
         if (two_stage || pools) {
             if (ix->fast_skip > 0) --ix->fast_skip; // (a recent call flagged too much for the fast scan to pay: plain mode 1)
@@ -1687,7 +1687,9 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
         // score, far enough below the k-th for the widened margin to certify nearly every query on well-separated data
         // (with K' = 8 pools 44 % of the queries of a Gaussian test set went to the second stage; pitch 1024 has no more).
         const bool hi_long = ix->hp > 0 && ix->hp <= 768;
-        bool fast = ix->plane > 0 && ix->hp > 0 && (hi_long || k <= 7) && ix->opt_f32_fast != 0 && ix->opt_margin != 0 && !split &&
+        // (row pitch 1024 has pools of 8 only: 46 % of a Gaussian test set went to the second stage -- stage 1 does not pay
+        // there unless asked for with "f32_fast" = 2)
+        bool fast = ix->plane > 0 && ix->hp > 0 && (hi_long || (k <= 7 && ix->opt_f32_fast == 2)) && ix->opt_f32_fast != 0 && ix->opt_margin != 0 && !split &&
                     (ix->opt_f32_fast == 2 || !out_dev || ix->opt_margin >= 2);
         if (fast && ix->opt_f32_fast == 1 && ix->fast_skip > 0) {
             --ix->fast_skip;

@@ -908,15 +908,22 @@ def test_f32_exact_two_stage_search(n, nq, d, k, metric):
     s, i = ix.search(q[:5], k)                                    # (bf16 rows are converted lazily: more rows follow)
     ix.add(x[n // 3:])
     s, i = ix.search(q, k)
-    assert not ix.last_kernel.startswith("mips::scan_kernel<"), ix.last_kernel   # a query-stationary bf16 kernel
+    if d <= 768:
+        assert not ix.last_kernel.startswith("mips::scan_kernel<"), ix.last_kernel   # a query-stationary bf16 kernel
+    else:   # pitch 1024: pools of 8 only, stage 1 does not pay by default ...
+        assert ix.last_kernel.startswith("mips::scan_kernel<")
+        ix.set_param("f32_fast", 2)                               # ... but can be asked for
+        s, i = ix.search(q, k)
+        assert not ix.last_kernel.startswith("mips::scan_kernel<")
     assert np.array_equal(i, ei) and np.array_equal(s, es)
     st = ix.margin_stats()
     assert st["flagged"] >= 0 and st["rescanned"] == st["flagged"] and st["unresolved"] == 0
     print("two-stage:", n, nq, d, k, metric, ix.last_kernel, st)
     assert st["flagged"] < (nq // 2 if d > 768 else max(2, nq // 10))   # Gaussian rows: stage 1 certifies nearly all (K' = 32 pools)
     qd = torch.from_numpy(q).cuda()
+    ix.set_param("f32_fast", 1)
     sd, idd = ix.search(qd, k)                                    # device outputs: two-stage as well, certified on the stream
-    if d <= 768:                                                  # (pitch 1024: pools of 8 flag too much, stage 1 is being skipped)
+    if d <= 768:                                                  # (pitch 1024: pools of 8 flag too much, no stage 1 by default)
         assert not ix.last_kernel.startswith("mips::scan_kernel<")   # default margin mode: nothing synchronises
         st_d = ix.margin_stats()
         assert st_d["rescanned"] == st_d["flagged"] and st_d["unresolved"] == 0
