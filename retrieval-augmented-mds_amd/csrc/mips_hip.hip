@@ -155,6 +155,7 @@ struct mips_index {
     int opt_margin = 1;
     Buffer mbnd, mflag, qbuf2, qf32b, tmp_s, tmp_i, ids, qhi, qerr2, keyk, qqv, hit_d, hit_i, hit_n;
     int opt_resolve = 1; // flagged queries: 1 = exact brute-force resolution (resolve_kernels.hpp), 0 = re-scan with the widest lists
+    int resolve_budget = 0; // > 0: flagged queries this search resolves at most (set per call; 0 = RESOLVE_MAX)
     double* xmax2_dev = nullptr; // max_i |x_i|^2 of the LOCAL rows, on the device (no host copy: never synchronises)
     bool xmax2_valid = false;
     unsigned* nflag_host = nullptr; // pinned: flagged-query count of the last certified search
@@ -1000,6 +1001,7 @@ int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
     a.ntotal = ix->ntotal;
     a.ids = ids;
     a.n_dev = cnt;
+    a.max_n = ix->resolve_budget > 0 ? std::min(ix->resolve_budget, mips::RESOLVE_MAX) : mips::RESOLVE_MAX;
     a.keyk = (const float*)ix->keyk.p;
     a.qq = (const double*)ix->qqv.p;
     a.phi = ix->phi;
@@ -1621,7 +1623,10 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
     struct MarginScope {
         mips_index* ix;
         int keep;
-        ~MarginScope() { ix->opt_margin = keep; }
+        ~MarginScope() {
+            ix->opt_margin = keep;
+            ix->resolve_budget = 0;
+        }
     } margin_scope{ix, ix->opt_margin};
     {   // the last stream-ordered certification's counts, if they have arrived (host-visible words, no synchronisation): a search
         // that flagged a large share of its queries or left some unresolved switches the optimistic scans off for a while
@@ -1641,8 +1646,11 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
         } else if ((double)nq * (double)ix->ntotal * (double)ix->ld >= 1.5e12 && (ix->plane > 0 ? ix->plane : ix->ld) <= 1024) {
             // a scan of milliseconds (half of BASELINE config 2 and up): the handful of launches of the stream-ordered
             // certificate -- tens of microseconds when nothing is flagged -- is below 1 % of it, so large searches are
-            // exact without a caveat by default (split-tail searches: on the tail stream)
+            // exact without a caveat by default (split-tail searches: on the tail stream).  Nobody asked for it, so it may
+            // not cost much either: up to 64 flagged queries (8 passes over the index) are settled, a search that flags more
+            // -- floods of exact or near ties -- keeps its first results and counts them, as mode 1 always did
             ix->opt_margin = 3;
+            ix->resolve_budget = 64;
         }
     }
     if (!done) {

@@ -39,6 +39,7 @@ struct ResolveArgs {
     int64_t ntotal;
     const int* ids;       // [n] flagged query numbers, ascending
     const int* n_dev;     // n
+    int max_n;            // resolve only if n <= max_n (<= RESOLVE_MAX): a search that flags more keeps its first results, counted unresolved
     const float* keyk;    // [nq] canonical key of the query's current k-th result (IP: score; L2: -distance)
     const double* qq;     // [nq] |q|^2 (L2)
     double phi;
@@ -65,7 +66,7 @@ template <typename EL, bool L2>
 __global__ __launch_bounds__(64 * RESOLVE_WAVES) void exact_filter_kernel(ResolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n = *a.n_dev;
-    if (n == 0 || n > RESOLVE_MAX) return;
+    if (n == 0 || n > a.max_n) return;
     constexpr int PER = EL::PER16;               // elements per 16-byte chunk
     constexpr int TCH = 8;                       // chunks per row per tile step: 128 bytes
     double* yd = reinterpret_cast<double*>(smem);                                   // [RESOLVE_QB][ld] queries of the batch, fp64
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(64) void resolve_finalize_kernel(ResolveArgs a) {
     const int j = blockIdx.x, lane = threadIdx.x;
     const int nall = *a.n_dev;
     if (j >= nall) return;
-    if (nall > RESOLVE_MAX) { // more than one search resolves: nothing was computed
+    if (nall > a.max_n) { // more than this search resolves: nothing was computed
         if (lane == 0) atomicAdd(a.unresolved, 1u);
         return;
     }
