@@ -277,12 +277,14 @@ int mips_index_check_error(mips_index_t* index, int synchronize, void* hip_strea
  * bound, documents dropped from a full running list) and FLAGS the query when B + e >= tk, e = d 2^-23 |q| max|x|
  * (a rigorous bound for fp32 accumulation of the exact bf16 / e4m3 products).  "margin_check" (mips_index_set_param):
  *   0  off;
- *   1  (default) flag and count on the device -- nothing synchronises; read the count with this call.  Exception: where
- *      a certificate buys a faster scan (fp32-exact index; 8 <= k <= 13 on a bf16 index at row pitch 384 .. 768) device-output
- *      searches behave as in mode 3 -- still without synchronising; "f32_fast" = 0 keeps them on the plain scans -- and so
- *      do searches whose scan takes milliseconds (nq x rows x d >= 1.5e12: from half of a 4096 x 2^20 x 768 search up),
- *      where the certificate's launches cost less than 1 % -- with a budget: a search that flags more than nq / 128 queries (at least 8, at most 64)
- *      (floods of exact or near ties) keeps its first results and counts them unresolved;
+ *   1  (default) flag and count on the device -- nothing synchronises; read the count with this call.  Two exceptions,
+ *      both still without synchronising, where device-output searches behave as in mode 3:
+ *      - where a certificate buys a faster scan (fp32-exact index with d <= 768; 8 <= k <= 13 on a bf16 index at row
+ *        pitch 384 .. 768); "f32_fast" = 0 keeps those on the plain scans;
+ *      - searches whose scan takes milliseconds (nq x rows x d >= 1.5e12: from half of a 4096 x 2^20 x 768 search up),
+ *        where the certificate's launches cost less than 1 % -- with a budget: a search that flags more than nq / 128
+ *        queries (at least 8, at most 64: floods of exact or near ties) keeps its first results and counts them
+ *        unresolved;
  *   2  certify: flagged queries are settled EXACTLY -- one pass over the stored rows per 8 flagged queries computes the
  *      canonical scores by brute force (csrc/resolve_kernels.hpp) and the rows reaching the current k-th result are ranked
  *      over it -- and mips_search synchronises to read the counts.  Searches into HOST buffers synchronise anyway and always
@@ -291,14 +293,14 @@ int mips_index_check_error(mips_index_t* index, int synchronize, void* hip_strea
  *   3  the same WITHOUT synchronising (device outputs): flag list and count live on the device, the passes are enqueued
  *      behind the first scan and leave at once when nothing is flagged (tens of microseconds).  Searches in this mode
  *      also take the optimistic / two-stage paths ("f32_fast") and never the one-launch kernel; split-tail searches
- *      (mips_search_split) run the passes on their tail stream; more than 1024 flagged queries stay unresolved (counted).  Host-buffer searches
- *      behave as in mode 2.
+ *      (mips_search_split) run the passes on their tail stream; more than 1024 flagged queries stay unresolved
+ *      (counted).  Host-buffer searches behave as in mode 2.
  * Outputs of the LAST search on the index: flagged = queries flagged by the first pass (-1: only counted on the
  * device and synchronize == 0), rescanned = queries settled exactly (or re-scanned), unresolved = queries left with their
  * first result: more than 64 rows tie with the k-th result exactly, or the search flagged more than it resolves (on tie-free
  * data the first result is exact in practice -- the MFMA error observed is ~sqrt(d) 2^-24, two orders of magnitude below
- * the bound).  Nothing in the reference corresponds (faiss IndexFlat
- * computes its scores in fp32 as well and offers no certificate). */
+ * the bound).  Nothing in the reference corresponds (faiss IndexFlat computes its scores in fp32 as well and offers no
+ * certificate). */
 int mips_index_margin_stats(mips_index_t* index, int64_t* flagged, int64_t* rescanned, int64_t* unresolved,
                             int synchronize, void* hip_stream);
 
