@@ -683,6 +683,13 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             return MIPS_OK;
         };
         int rc2;
+#ifdef MIPS_EXPERIMENTAL
+        if (ix->ld == 768 && ix->opt_sub == 51) { // ring-depth experiment (profiles/r2_pitch1024): the same kernel on a 2-stage ring
+            rc2 = go4(mips::scan_kernel_v3<KL, 48, 1, 4, true, 0, 2, 4, 2>);
+            if (rc2) return rc2;
+            set_kernel_name(ix, "mips::scan_kernel_v3 experimental instance sub=51 (4 waves, 2 stages)");
+        } else
+#endif
         if (nqt == 1) { // one query tile: non-temporal document DMA
             if (ix->ld == 768) rc2 = go4(mips::scan_kernel_v3<KL, 48, 1, 4, true, 0, 2, 4, 3, true, true>);
             else if (ix->ld == 512) rc2 = go4(mips::scan_kernel_v3<KL, 32, 1, 4, true, 0, 2, 4, 3, true, true>);

@@ -24,9 +24,9 @@ res = {v: [] for v in a.variants}
 for r in range(a.rounds):
     for v in a.variants:
         params = dict(kv.split("=") for kv in v.split(",") if kv)
-        for name in ("nsplit", "qgroups", "variant", "sub"):
+        for name in ("nsplit", "qgroups", "variant", "sub", "optimistic"):
             try:
-                ix.set_param(name, int(params.get(name, 0)))
+                ix.set_param(name, int(params.get(name, 1 if name == "optimistic" else 0)))
             except RuntimeError:
                 pass
         s, i = ix.search(q, a.k); torch.cuda.synchronize()
