@@ -282,9 +282,9 @@ int mips_index_check_error(mips_index_t* index, int synchronize, void* hip_strea
  *      - where a certificate buys a faster scan (fp32-exact index with d <= 768; 8 <= k <= 13 on a bf16 index at row
  *        pitch 384 .. 768); "f32_fast" = 0 keeps those on the plain scans;
  *      - searches whose scan takes milliseconds (nq x rows x d >= 1.5e12: from half of a 4096 x 2^20 x 768 search up),
- *        where the certificate's launches cost less than 1 % -- with a budget: a search that flags more than nq / 128
- *        queries (at least 8, at most 64: floods of exact or near ties) keeps its first results and counts them
- *        unresolved;
+ *        where the certificate's launches cost less than 1 % -- with a budget: a search that flags more than nq / 512
+ *        queries (at least 8, at most 16: one or two passes; near-duplicate-heavy data) keeps its first results and
+ *        counts them unresolved -- "margin_check" = 3 lifts the budget to 1024;
  *   2  certify: flagged queries are settled EXACTLY -- one pass over the stored rows per 8 flagged queries computes the
  *      canonical scores by brute force (csrc/resolve_kernels.hpp) and the rows reaching the current k-th result are ranked
  *      over it -- and mips_search synchronises to read the counts.  Searches into HOST buffers synchronise anyway and always

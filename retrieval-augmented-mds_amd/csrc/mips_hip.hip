@@ -1654,11 +1654,12 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
             // a scan of milliseconds (half of BASELINE config 2 and up): the handful of launches of the stream-ordered
             // certificate -- tens of microseconds when nothing is flagged -- is below 1 % of it, so large searches are
             // exact without a caveat by default (split-tail searches: on the tail stream).  Nobody asked for it, so it may
-            // not cost much either (one pass over the index per 8 flagged queries costs as much as ~300 queries of the scan):
-            // up to nq / 128 flagged queries, at least 8 and at most 64, are settled; a search that flags more -- floods of
-            // exact or near ties -- keeps its first results and counts them, as mode 1 always did
+            // not cost much either (one pass over the index per 8 flagged queries costs as much as ~600 queries of the bf16
+            // scan: +14 % on a 4096-query search): up to nq / 512 flagged queries, at least 8 and at most 16 -- one or two
+            // passes -- are settled; a search that flags more (near-duplicate-heavy data, floods of ties) keeps its first
+            // results and counts them, as mode 1 always did.  "margin_check" = 3 lifts the budget to 1024.
             ix->opt_margin = 3;
-            ix->resolve_budget = (int)std::max<int64_t>(8, std::min<int64_t>(64, nq / 128));
+            ix->resolve_budget = (int)std::max<int64_t>(8, std::min<int64_t>(16, nq / 512));
         }
     }
     if (!done) {
