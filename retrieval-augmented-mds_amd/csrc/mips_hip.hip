@@ -1034,7 +1034,7 @@ int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
     else if (ix->esize == 1) rc = l2 ? go(mips::exact_filter_kernel<mips::ElemF8, true>) : go(mips::exact_filter_kernel<mips::ElemF8, false>);
     else rc = l2 ? go(mips::exact_filter_kernel<mips::ElemBF16, true>) : go(mips::exact_filter_kernel<mips::ElemBF16, false>);
     if (rc) return rc;
-    const int fgrid = (int)std::min<int64_t>(nq, certify_now ? (int64_t)ix->nflag_host[0] : nq);
+    const int fgrid = (int)std::min<int64_t>(nq, certify_now ? (int64_t)ix->nflag_host[0] : (int64_t)a.max_n); // (at least one block: it counts an over-budget search)
     if (l2) mips::resolve_finalize_kernel<true><<<fgrid, 64, 0, st>>>(a);
     else mips::resolve_finalize_kernel<false><<<fgrid, 64, 0, st>>>(a);
     HIP_TRY(hipGetLastError());

@@ -157,8 +157,8 @@ __global__ __launch_bounds__(64) void resolve_finalize_kernel(ResolveArgs a) {
     const int j = blockIdx.x, lane = threadIdx.x;
     const int nall = *a.n_dev;
     if (j >= nall) return;
-    if (nall > a.max_n) { // more than this search resolves: nothing was computed
-        if (lane == 0) atomicAdd(a.unresolved, 1u);
+    if (nall > a.max_n) { // more than this search resolves: nothing was computed (the grid only covers max_n queries)
+        if (j == 0 && lane == 0) atomicAdd(a.unresolved, (unsigned)nall);
         return;
     }
     const int c = a.hit_n[j];
