@@ -416,6 +416,10 @@ struct MergeArgs {
     const int* nq_dev = nullptr;   // stream-ordered re-scan: the query count lives on the device (launches sized for the maximum)
     float* keyk = nullptr;         // [nq] out: canonical key of the k-th result (+inf: fewer than k results) -- resolve_kernels.hpp
     double* qq_out = nullptr;      // [nq] out: |q|^2 as the re-score summed it
+    // a second bound with an error constant of its own (tiny_search.hpp, fp32-exact index): bnd2[q] = best REFINED score outside
+    // the pool (fp32 operands, fp64 sum, float32 storage: within err_c2 |q| max|x| of the canonical score)
+    const float* bnd2 = nullptr;
+    double err_c2 = 0.0;
 };
 
 // What a search whose scan kernel gave up (split-barrier spin bound, scan_kernel_v3.hpp) returns instead of
@@ -592,6 +596,10 @@ __device__ __forceinline__ void rank_flag_write(const MergeArgs& p, int64_t q, i
                     e += dr * sqrt(qn) + (sqrt(*p.xmax2) + dr) * sqrt(p.qerr2[q]);
                 }
                 fl = !((double)b + e < tk); // also true for NaN: never certify what cannot be compared
+            }
+            if (p.bnd2 != nullptr && have) {
+                const float b2 = p.bnd2[q];
+                if (b2 > -INFINITY) fl = fl || !((double)b2 + p.err_c2 * sqrt(qn) * sqrt(*p.xmax2) < tk);
             }
             p.flag[q] = fl ? 1 : 0;
             if (fl) atomicAdd(p.nflag, 1u);
@@ -899,8 +907,10 @@ __global__ void scatter_f32_kernel(const float* src, const int* ids, int64_t n, 
 
 // flagged queries -> ascending list of their numbers + count (one workgroup; stream-ordered re-scan)
 // zero / nzero: words the same launch clears for what follows (hit counters and the unresolved counter of the exact pass)
+// only_above >= 0: the count is written as 0 unless it exceeds only_above (the fall-back re-scan of a search that flagged more
+// queries than the exact pass resolves: its launches are sized by this gated count and leave at once otherwise)
 __global__ __launch_bounds__(256) void compact_flags_kernel(const unsigned char* flags, int nq, int* ids, int* count, int* zero = nullptr,
-                                                            int nzero = 0, unsigned* zero2 = nullptr) {
+                                                            int nzero = 0, unsigned* zero2 = nullptr, int only_above = -1) {
     __shared__ int part[256];
     const int t = threadIdx.x;
     for (int z = t; z < nzero; z += 256) zero[z] = 0;
@@ -920,7 +930,7 @@ __global__ __launch_bounds__(256) void compact_flags_kernel(const unsigned char*
     int w = part[t] - c;
     for (int q = lo; q < hi; ++q)
         if (flags[q]) ids[w++] = q;
-    if (t == 255) *count = part[255];
+    if (t == 255) *count = part[255] > only_above ? part[255] : 0;
 }
 
 __global__ void fill_empty_kernel(float* out_s, int64_t* out_i, int64_t* out_packed, int64_t total, int metric) {

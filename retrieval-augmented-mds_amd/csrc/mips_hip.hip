@@ -128,9 +128,10 @@ struct mips_index {
     // compacted on the device and the second scan, sized for all queries, lets the workgroups past the count leave
     const int* nq_dev = nullptr;         // launch_search: device-side query count of the re-scan in progress
     const int* first_nflag_dev = nullptr; // flagged count of the first scan of the last mode-3 search (margin stats)
-    int64_t stats_nq = 0;                 // queries of the last search whose resolve statistics went to sticky_host[2..3]
     int plane_keep = 0;
-    int fast_skip = 0;           // calls left to skip stage 1 for (the last one flagged too many queries to pay)
+    int fast_skip = 0;           // calls left to skip stage 1 for: set by a SYNCHRONISING call that flagged too many queries for the
+                                 // optimistic scan to pay (its count is known when it returns; stream-ordered calls never set it,
+                                 // so what a search does depends on the calls before it, not on when a device store lands)
     bool phi_valid = false;
     int call_metric = MIPS_METRIC_IP; // metric of the search in progress (index metric unless MIPS_FORCE_IP)
     bool phi_override = false; // phi was set from outside (global maximum of a sharded index): adds do not reset it
@@ -153,9 +154,11 @@ struct mips_index {
     // synchronise, re-scan the flagged queries with the widest lists.  Host-output searches always certify (they
     // synchronise anyway) unless the check is off.
     int opt_margin = 1;
-    Buffer mbnd, mflag, qbuf2, qf32b, tmp_s, tmp_i, ids, qhi, qerr2, keyk, qqv, hit_d, hit_i, hit_n;
+    Buffer mbnd, mflag, qbuf2, qf32b, tmp_s, tmp_i, ids, qhi, qerr2, keyk, qqv, hit_d, hit_i, hit_n, qnorm;
     int opt_resolve = 1; // flagged queries: 1 = exact brute-force resolution (resolve_kernels.hpp), 0 = re-scan with the widest lists
-    int resolve_budget = 0; // > 0: flagged queries this search resolves at most (set per call; 0 = RESOLVE_MAX)
+    int resolve_budget = 0; // "resolve_budget" > 0: flagged queries a search resolves at most (0 = RESOLVE_MAX); a search that flags
+                            // more keeps its first results (counted unresolved) -- or, if its first scan was an optimistic one,
+                            // goes through the stream-ordered re-scan with true K' = 32 lists
     double* xmax2_dev = nullptr; // max_i |x_i|^2 of the LOCAL rows, on the device (no host copy: never synchronises)
     bool xmax2_valid = false;
     unsigned* nflag_host = nullptr; // pinned: flagged-query count of the last certified search
@@ -851,13 +854,41 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
 // One-launch search for the reference's own call shape (tiny_search.hpp): <= 16 queries, bf16 index of at most
 // kTinyMaxRows rows, k_fetch <= 6.  q must be device memory.
 constexpr int64_t kTinyMaxRows = 1 << 16;
-bool tiny_eligible(const mips_index* ix, int64_t nq, int k_fetch) {
-    return ix->opt_tiny != 0 && nq >= 1 && nq <= 16 && k_fetch <= mips::TINY_MAXK && ix->ntotal > 0 && ix->ntotal <= kTinyMaxRows &&
-           ix->esize == 2 && ix->plane == 0 && ix->ld <= 1024 && ix->ld % 128 == 0 && ix->rescan_depth == 0;
+// certifies: the call settles the queries it flags (host buffers, "margin_check" = 2, or stream-ordered).  The fp32-exact
+// index takes the one-launch kernel only then: its scan sees bf16(x) . bf16(q) (stage 1 of the two-stage search), which is
+// admissible because of the certificate alone
+bool tiny_eligible(const mips_index* ix, int64_t nq, int k_fetch, bool certifies) {
+    if (!(ix->opt_tiny != 0 && nq >= 1 && nq <= 16 && k_fetch <= mips::TINY_MAXK && ix->ntotal > 0 && ix->ntotal <= kTinyMaxRows &&
+          ix->esize == 2 && ix->rescan_depth == 0))
+        return false;
+    if (ix->plane > 0) return certifies && ix->opt_f32_fast != 0 && ix->hp > 0 && ix->hp <= 1024 && ix->hp % 128 == 0;
+    return ix->ld <= 1024 && ix->ld % 128 == 0;
 }
 
+int ensure_resolve_buffers(mips_index* ix, int64_t nq) {
+    int rc = ix->ids.ensure((size_t)(nq + 4) * sizeof(int));
+    if (rc) return rc;
+    rc = ix->hit_d.ensure((size_t)mips::RESOLVE_MAX * mips::RESOLVE_CAP * sizeof(double));
+    if (rc) return rc;
+    rc = ix->hit_i.ensure((size_t)mips::RESOLVE_MAX * mips::RESOLVE_CAP * sizeof(int));
+    if (rc) return rc;
+    rc = ix->hit_n.ensure((size_t)mips::RESOLVE_MAX * sizeof(int));
+    if (rc) return rc;
+    rc = ix->keyk.ensure((size_t)nq * sizeof(float));
+    if (rc) return rc;
+    return ix->qqv.ensure((size_t)nq * sizeof(double));
+}
+
+// handoff: prepare the stream-ordered exact pass (resolve_flagged with skip_compact) -- the kernel's last workgroup writes
+// the flag list, clears the hit counters and copies the staged queries out when something was flagged
 int tiny_search(mips_index* ix, const void* q_dev, int q_dtype, int64_t nq, int k_fetch, int k_out, int normalize, const int64_t* ignore_dev,
-                float* d_s, int64_t* d_i, bool packed, int64_t idx_offset, hipStream_t st) {
+                float* d_s, int64_t* d_i, bool packed, int64_t idx_offset, hipStream_t st, bool handoff) {
+    const bool f32x = ix->plane > 0;
+    const int tld = f32x ? ix->hp : ix->ld; // row pitch of the scanned bf16 rows
+    if (f32x) { // bf16 rows + residual bound up to date, max |x|^2 on the fp32 rows
+        int rc0 = ensure_hi(ix, st);
+        if (rc0) return rc0;
+    }
     if (!ix->tiny_words) {
         HIP_TRY(hipMalloc((void**)&ix->tiny_words, 64));
         HIP_TRY(hipMemsetAsync(ix->tiny_words, 0, 64, st)); // the ticket starts at 0; the kernel's last workgroup resets it
@@ -867,14 +898,21 @@ int tiny_search(mips_index* ix, const void* q_dev, int q_dtype, int64_t nq, int 
     // the last one to sift; spreading thinner did not make the first tiles arrive sooner)
     const int nwg = (int)std::max<int64_t>(1, std::min<int64_t>(mips::TINY_MAX_WG, (ntiles + mips::TINY_WAVES - 1) / mips::TINY_WAVES));
     mips::TinyArgs a;
-    a.docs = (const uint16_t*)ix->rows;
+    a.docs = f32x ? (const uint16_t*)ix->rows_hi : (const uint16_t*)ix->rows;
+    a.rows_f32 = ix->rows_f32;
+    a.plane = ix->plane;
     a.q = q_dev;
     a.q_is_f32 = q_dtype == MIPS_DTYPE_F32 ? 1 : 0;
     a.normalize = normalize;
     a.nq = (int)nq;
     a.d = (int)ix->d;
-    a.ld = ix->ld;
+    a.ld = tld;
     a.ntotal = ix->ntotal;
+    a.res_ids = nullptr;
+    a.res_cnt = nullptr;
+    a.res_hit_n = nullptr;
+    a.res_unres = nullptr;
+    a.q_out = nullptr;
     a.ntiles = ntiles;
     a.nwaves = nwg * mips::TINY_WAVES;
     a.force_slow = ix->opt_tiny == 2 ? 1 : 0;
@@ -895,9 +933,9 @@ int tiny_search(mips_index* ix, const void* q_dev, int q_dtype, int64_t nq, int 
     m.ncand = (int)ncand;
     m.pre_bnd = (const float*)ix->part_s.p + 16 * ncand;
     m.npre = nwg;
-    m.docs = ix->rows;
+    m.docs = a.docs;
     m.qbuf = nullptr;
-    m.ld = ix->ld;
+    m.ld = tld;
     m.k = k_fetch;
     m.metric = ix->call_metric;
     m.phi = ix->phi;
@@ -912,11 +950,13 @@ int tiny_search(mips_index* ix, const void* q_dev, int q_dtype, int64_t nq, int 
     m.flag = nullptr;
     m.nflag = nullptr;
     m.xmax2 = ix->xmax2_dev;
-    m.err_c = (double)ix->d * 1.1920928955078125e-07;
+    m.err_c = (double)ix->d * 1.1920928955078125e-07 * (f32x ? 1.01 : 1.0); // (F32: the scan's operands are bf16(q), bf16(x))
+    m.dres2 = ix->dres2_dev;
     ix->last_flagged = -1;
     ix->last_rescanned = 0;
     ix->last_unresolved = 0;
     ix->last_nflag_dev = nullptr;
+    ix->first_nflag_dev = nullptr;
     if (ix->opt_margin != 0) {
         rc = ix->mbnd.ensure(16 * sizeof(float));
         if (rc) return rc;
@@ -929,8 +969,24 @@ int tiny_search(mips_index* ix, const void* q_dev, int q_dtype, int64_t nq, int 
         m.flag = (unsigned char*)ix->mflag.p;
         m.nflag = ix->tiny_words + 1;
         ix->last_nflag_dev = m.nflag;
+        if (handoff) {
+            rc = ensure_resolve_buffers(ix, nq);
+            if (rc) return rc;
+            if (f32x) rc = ix->qf32.ensure((size_t)16 * ix->plane * sizeof(float));
+            else rc = ix->qbuf.ensure((size_t)16 * ix->ld * 2);
+            if (rc) return rc;
+            a.res_ids = (int*)ix->ids.p;
+            a.res_cnt = a.res_ids + nq;
+            a.res_unres = (unsigned*)(a.res_ids + nq + 1);
+            a.res_hit_n = (int*)ix->hit_n.p;
+            a.q_out = f32x ? ix->qf32.p : ix->qbuf.p;
+            m.keyk = (float*)ix->keyk.p;
+            m.qq_out = (double*)ix->qqv.p;
+        }
+    } else if (f32x) {
+        return fail(MIPS_E_INVALID, "tiny_search: the fp32-exact index needs the margin check");
     }
-    const int lds = mips::tiny_lds_bytes(ix->ld);
+    const int lds = mips::tiny_lds_bytes(tld, ix->plane);
 #ifdef MIPS_EXPERIMENTAL
     static unsigned long long* dbg_dev = nullptr;
     const bool dbg = getenv("MIPS_TINY_DBG") != nullptr;
@@ -938,12 +994,15 @@ int tiny_search(mips_index* ix, const void* q_dev, int q_dtype, int64_t nq, int 
     a.dbg = dbg ? dbg_dev : nullptr;
     if (dbg) HIP_TRY(hipMemsetAsync(dbg_dev, 0, 256 * 16 * 8, st));
 #endif
-    if (lds > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute((const void*)mips::tiny_search_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)mips::tiny_search_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    }
-    if (ix->call_metric == MIPS_METRIC_L2) mips::tiny_search_kernel<true><<<nwg, mips::TINY_THREADS, lds, st>>>(a);
-    else mips::tiny_search_kernel<false><<<nwg, mips::TINY_THREADS, lds, st>>>(a);
+    auto go = [&](auto kern) -> int {
+        if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        kern<<<nwg, mips::TINY_THREADS, lds, st>>>(a);
+        return MIPS_OK;
+    };
+    const bool l2m = ix->call_metric == MIPS_METRIC_L2;
+    if (f32x) rc = l2m ? go(mips::tiny_search_kernel<true, true>) : go(mips::tiny_search_kernel<false, true>);
+    else rc = l2m ? go(mips::tiny_search_kernel<true, false>) : go(mips::tiny_search_kernel<false, false>);
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
 #ifdef MIPS_EXPERIMENTAL
     if (dbg) { // phase stamps (10 ns units) relative to the first workgroup's start: the slowest workgroup per phase and the last one
@@ -965,7 +1024,7 @@ int tiny_search(mips_index* ix, const void* q_dev, int q_dtype, int64_t nq, int 
                 (double)(h[last * 16 + 13] - h[last * 16 + 12]) / ((double)(h[last * 16 + 11] - h[last * 16]) * 0.01));
     }
 #endif
-    set_kernel_name(ix, "mips::tiny_search_kernel<%s>", ix->call_metric == MIPS_METRIC_L2 ? "true" : "false");
+    set_kernel_name(ix, "mips::tiny_search_kernel<%s, %s>", l2m ? "true" : "false", f32x ? "true" : "false");
     return MIPS_OK;
 }
 
@@ -975,21 +1034,18 @@ int tiny_search(mips_index* ix, const void* q_dev, int q_dtype, int64_t nq, int 
 // flagged more than RESOLVE_MAX queries is handed to the tile re-scan (return value kUseRescan).  Otherwise everything is
 // enqueued blind; the counts travel to host-visible words for the next search to look at (mips_index::stats_host).
 constexpr int kUseRescan = 1;
+// skip_compact: the flag list, its count and the cleared counters are already on the device (the one-launch kernel's hand-off).
+// ignore / k_out: the fused hook call's ignore filter (ResolveArgs), d_s / d_i then are [nq][k_out].
 int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, bool packed, int64_t idx_offset, hipStream_t st, bool certify_now,
-                    bool first_was_optimistic) {
-    int rc = ix->ids.ensure((size_t)(nq + 4) * sizeof(int));
+                    bool skip_compact = false, const int64_t* ignore = nullptr, int k_out = 0) {
+    int rc = ensure_resolve_buffers(ix, nq); // (never reallocates behind a hand-off: same sizes as tiny_search asked for)
     if (rc) return rc;
     int* ids = (int*)ix->ids.p;
     int* cnt = ids + nq;
     unsigned* unres = (unsigned*)(ids + nq + 1);
-    rc = ix->hit_d.ensure((size_t)mips::RESOLVE_MAX * mips::RESOLVE_CAP * sizeof(double));
-    if (rc) return rc;
-    rc = ix->hit_i.ensure((size_t)mips::RESOLVE_MAX * mips::RESOLVE_CAP * sizeof(int));
-    if (rc) return rc;
-    rc = ix->hit_n.ensure((size_t)mips::RESOLVE_MAX * sizeof(int));
-    if (rc) return rc;
     if (!ix->nflag_host) HIP_TRY(hipHostMalloc((void**)&ix->nflag_host, 64, hipHostMallocDefault));
-    mips::compact_flags_kernel<<<1, 256, 0, st>>>((const unsigned char*)ix->mflag.p, (int)nq, ids, cnt, (int*)ix->hit_n.p, mips::RESOLVE_MAX, unres);
+    if (!skip_compact)
+        mips::compact_flags_kernel<<<1, 256, 0, st>>>((const unsigned char*)ix->mflag.p, (int)nq, ids, cnt, (int*)ix->hit_n.p, mips::RESOLVE_MAX, unres);
     if (certify_now) {
         HIP_TRY(hipMemcpyAsync(&ix->nflag_host[0], cnt, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -1021,6 +1077,8 @@ int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
     a.out_i = d_i;
     a.out_packed = packed ? d_i : nullptr;
     a.unresolved = unres;
+    a.ignore = ignore;
+    a.k_out = ignore ? k_out : 0;
     const int lds = mips::RESOLVE_QB * a.ld * (int)sizeof(double) + mips::RESOLVE_WAVES * 64 * 9 * 16;
     const int rows_per_wg = 64 * mips::RESOLVE_WAVES;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (ix->ntotal + rows_per_wg - 1) / rows_per_wg));
@@ -1046,12 +1104,7 @@ int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
         ix->last_rescanned = ix->last_flagged;
         ix->last_unresolved = (int64_t)ix->nflag_host[1];
     } else {
-        ix->last_flagged = -1;
-        if (first_was_optimistic) { // (only the optimistic scans are steered by what the last search flagged)
-            ix->stats_nq = nq;
-            mips::publish_resolve_stats_kernel<<<1, 1, 0, st>>>(cnt, unres, ix->sticky_dev + 2);
-            HIP_TRY(hipGetLastError());
-        }
+        ix->last_flagged = -1; // (device only: mips_index_margin_stats fetches the two counters when asked)
     }
     return MIPS_OK;
 }
@@ -1061,25 +1114,32 @@ int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
 // (widest lists) is launched for ALL nq queries' worth of workgroups, which read the count and leave when they are past it
 // (ScanArgs::nq_dev); select, re-score and the scatter over the first results do the same.  With nothing flagged this costs
 // a handful of empty launches (tens of microseconds); mips_index_margin_stats reads both counters when asked.
+// gate_above >= 0: the fall-back behind the exact pass for searches whose FIRST scan was an optimistic one (two-stage fp32 search,
+// pools of 32 out of sub-lists): the exact pass leaves a search that flagged more than gate_above queries alone, and first results
+// selected by bf16 scores / short sub-lists must not stand uncertified -- so this re-scan runs exactly then (its launches are
+// sized by a count that is 0 otherwise) and its own still-flagged count replaces the exact pass's "unresolved".
 template <int KL>
-int rescan_on_stream(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, bool packed, int64_t idx_offset, hipStream_t st, bool fast_first) {
+int rescan_on_stream(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, bool packed, int64_t idx_offset, hipStream_t st, bool fast_first,
+                     int gate_above = -1) {
     const bool f8 = ix->esize == 1;
     const int wide = f8 ? (KL < 16 ? 16 : 0) : (KL < 32 || fast_first ? 32 : 0);
-    ix->last_flagged = -1; // (device only)
+    if (gate_above < 0) ix->last_flagged = -1; // (device only)
     if (wide == 0) return MIPS_OK; // already on the widest lists: counted only
     const int64_t n_pad = round_up(nq, kQueryAlign);
     const size_t row_bytes = (size_t)ix->ld * ix->esize;
     int rc = ix->ids.ensure((size_t)(nq + 4) * sizeof(int));
     if (rc) return rc;
     int* ids = (int*)ix->ids.p;
-    int* cnt = ids + nq;
+    int* cnt = ids + nq + (gate_above >= 0 ? 2 : 0); // (gated: the exact pass's own count and unresolved counter stay where they are)
+    unsigned* const exact_unres = (unsigned*)(ids + nq + 1);
+    const int* const first_keep = ix->first_nflag_dev;
     rc = ix->qbuf2.ensure((size_t)n_pad * row_bytes);
     if (rc) return rc;
     rc = ix->tmp_s.ensure((size_t)nq * k * sizeof(float));
     if (rc) return rc;
     rc = ix->tmp_i.ensure((size_t)nq * k * sizeof(int64_t) * 2);
     if (rc) return rc;
-    mips::compact_flags_kernel<<<1, 256, 0, st>>>((const unsigned char*)ix->mflag.p, (int)nq, ids, cnt);
+    mips::compact_flags_kernel<<<1, 256, 0, st>>>((const unsigned char*)ix->mflag.p, (int)nq, ids, cnt, nullptr, 0, nullptr, gate_above);
     mips::gather_rows_kernel<<<grid_for(n_pad * (int64_t)(row_bytes / 16), 256), 256, 0, st>>>((const unsigned char*)ix->qbuf.p, ids, 0, n_pad, (int)row_bytes,
                                                                                               (unsigned char*)ix->qbuf2.p, cnt);
     if (ix->plane > 0) {
@@ -1120,6 +1180,13 @@ int rescan_on_stream(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i
         mips::scatter_f32_kernel<<<grid_for(nq * k, 256), 256, 0, st>>>(ts, ids, 0, k, d_s, cnt);
     }
     HIP_TRY(hipGetLastError());
+    if (gate_above >= 0) { // statistics stay the exact pass's; if this re-scan ran, what IT still flags is what is unresolved
+        mips::adopt_rescan_count_kernel<<<1, 1, 0, st>>>(cnt, ix->last_nflag_dev, exact_unres);
+        HIP_TRY(hipGetLastError());
+        ix->first_nflag_dev = first_keep;
+        ix->last_nflag_dev = exact_unres;
+        return MIPS_OK;
+    }
     ix->first_nflag_dev = (const int*)cnt; // last_nflag_dev: the re-scan's own counter (still flagged on the widest lists)
     return MIPS_OK;
 }
@@ -1141,7 +1208,12 @@ int finish_margin(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, b
     // flagged queries are settled exactly, by brute force on the canonical scores (rows of up to 1024 columns; beyond that
     // -- and with "resolve" = 0 -- by the re-scan with the widest lists below)
     if (ix->opt_resolve != 0 && (ix->plane > 0 ? ix->plane : ix->ld) <= 1024) {
-        const int r = resolve_flagged(ix, nq, k, d_s, d_i, packed, idx_offset, st, !(out_dev && ix->opt_margin == 3), fast_first);
+        const bool stream_ordered = out_dev && ix->opt_margin == 3;
+        const int r = resolve_flagged(ix, nq, k, d_s, d_i, packed, idx_offset, st, !stream_ordered);
+        if (r == MIPS_OK && stream_ordered && fast_first) {
+            const int max_n = ix->resolve_budget > 0 ? std::min(ix->resolve_budget, mips::RESOLVE_MAX) : mips::RESOLVE_MAX;
+            if (nq > max_n) return rescan_on_stream<KL>(ix, nq, k, d_s, d_i, packed, idx_offset, st, fast_first, max_n);
+        }
         if (r != kUseRescan) return r;
         ix->first_nflag_dev = nullptr; // (more flagged than the exact pass takes: the tile re-scan below, which synchronises)
     } else if (out_dev && ix->opt_margin == 3) {
@@ -1264,7 +1336,7 @@ int scan_and_finish(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
         ix->last_flagged = -1;
         ix->first_nflag_dev = nullptr;
         if (ix->opt_margin == 3 && out_dev && ix->opt_resolve != 0 && (ix->plane > 0 ? ix->plane : ix->ld) <= 1024) {
-            rc = resolve_flagged(ix, nq, k, d_s, d_i, packed, idx_offset, tail_st, false, false);
+            rc = resolve_flagged(ix, nq, k, d_s, d_i, packed, idx_offset, tail_st, false);
             if (rc) return rc;
             HIP_TRY(hipEventRecord(ix->tail_done[ix->cur_set], tail_st)); // (supersedes the record behind the re-score: the exact
             ix->tail_pending[ix->cur_set] = true;                         // pass reads this set's staged queries)
@@ -1277,6 +1349,20 @@ int scan_and_finish(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
     if (!rc && first_was_optimistic && ix->opt_f32_fast != 2 && ix->last_flagged >= 64 && ix->last_flagged * 8 > nq) ix->fast_skip = 8;
     return rc;
 }
+
+// "margin_check" as the caller set it -> the mode the code below acts on, for the duration of one call:
+//   1 (default, "auto")  device outputs: 3 = certify on the stream; host buffers: they synchronise anyway and certify
+//   4 ("count only")     1 in the code below: device outputs count flagged queries, nothing more
+// 0 / 2 / 3 as they are.  Restored when the call returns.
+struct MarginScope {
+    mips_index* ix;
+    int keep;
+    MarginScope(mips_index* ix_, bool out_dev) : ix(ix_), keep(ix_->opt_margin) {
+        if (keep == 1 && out_dev) ix->opt_margin = 3;
+        else if (keep == 4) ix->opt_margin = 1;
+    }
+    ~MarginScope() { ix->opt_margin = keep; }
+};
 
 } // namespace
 
@@ -1382,6 +1468,7 @@ int mips_index_destroy(mips_index_t* ix) {
     ix->hit_d.release();
     ix->hit_i.release();
     ix->hit_n.release();
+    ix->qnorm.release();
     for (int e = 0; e < mips_index::kEvRing; ++e) {
         if (ix->ev0[e]) (void)hipEventDestroy(ix->ev0[e]);
         if (ix->ev1[e]) (void)hipEventDestroy(ix->ev1[e]);
@@ -1593,13 +1680,15 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
         d_i = (int64_t*)ix->out_i.p;
     }
 
+    MarginScope margin_scope(ix, out_dev);
+    const bool certifies = ix->opt_margin != 0 && (!out_dev || ix->opt_margin >= 2);
     bool done = false;
     if (ix->ntotal == 0) {
         const int64_t total = nq * k;
         mips::fill_empty_kernel<<<(int)((total + 255) / 256), 256, 0, st>>>(d_s, d_i, packed ? d_i : nullptr, total, ix->call_metric);
         HIP_TRY(hipGetLastError());
         done = true;
-    } else if (tiny_eligible(ix, nq, k) && !(out_dev && ix->opt_margin == 3)) { // (mode 3 re-scans on the stream: general path)
+    } else if (tiny_eligible(ix, nq, k, certifies)) {
         // the reference's own call shape (<= 16 queries, small knowledge base): one launch (tiny_search.hpp)
         if (ix->call_metric == MIPS_METRIC_L2) {
             int rc = compute_phi(ix, st);
@@ -1613,53 +1702,21 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
             HIP_TRY(hipMemcpyAsync(ix->stage.p, q, qbytes, hipMemcpyHostToDevice, st));
             qd = ix->stage.p;
         }
-        int rc = tiny_search(ix, qd, q_dtype, nq, k, k, 0, nullptr, d_s, d_i, packed, idx_offset, st);
+        const bool stream_ordered = out_dev && ix->opt_margin == 3;
+        int rc = tiny_search(ix, qd, q_dtype, nq, k, k, 0, nullptr, d_s, d_i, packed, idx_offset, st, stream_ordered);
         if (rc) return rc;
         done = true;
-        if (ix->opt_margin != 0 && !split && (!out_dev || ix->opt_margin == 2)) {
+        if (stream_ordered) { // the exact pass behind the one launch: leaves at once when nothing was flagged (the kernel, and
+            // with it its results, live on the scan stream even in the split-tail form)
+            rc = resolve_flagged(ix, nq, k, d_s, d_i, packed, idx_offset, st, false, /*skip_compact=*/true);
+            if (rc) return rc;
+        } else if (ix->opt_margin != 0 && (!out_dev || ix->opt_margin == 2)) {
             // certify: a flagged query sends the whole (tiny) call through the general path and its re-scan
             if (!ix->nflag_host) HIP_TRY(hipHostMalloc((void**)&ix->nflag_host, 64, hipHostMallocDefault));
             HIP_TRY(hipMemcpyAsync(ix->nflag_host, ix->last_nflag_dev, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             ix->last_flagged = (int64_t)ix->nflag_host[0];
             done = ix->last_flagged == 0;
-        }
-    }
-    // Default margin mode (1 = count only): where a certificate buys a faster scan -- fp32-exact index (two-stage search),
-    // 8 <= k <= 13 on a bf16 index (optimistic pools) -- device-output searches certify on the stream (mode 3) instead.
-    struct MarginScope {
-        mips_index* ix;
-        int keep;
-        ~MarginScope() {
-            ix->opt_margin = keep;
-            ix->resolve_budget = 0;
-        }
-    } margin_scope{ix, ix->opt_margin};
-    {   // the last stream-ordered certification's counts, if they have arrived (host-visible words, no synchronisation): a search
-        // that flagged a large share of its queries or left some unresolved switches the optimistic scans off for a while
-        const unsigned fl = ix->sticky_host[2], un = ix->sticky_host[3];
-        if (fl != 0u || un != 0u) {
-            if (un > 0u || (fl >= 64u && (int64_t)fl * 8 > ix->stats_nq)) ix->fast_skip = 8;
-            ix->sticky_host[2] = 0u;
-            ix->sticky_host[3] = 0u;
-        }
-    }
-    if (!done && ix->opt_margin == 1 && out_dev && ix->opt_f32_fast == 1) {
-        const bool two_stage = !split && ix->plane > 0 && ix->hp > 0 && ix->hp <= 768;
-        const bool pools = !split && ix->plane == 0 && ix->esize == 2 && k >= 8 && k <= 13 && ix->ld % 128 == 0 && ix->ld >= 384 && ix->ld <= 768;
-        if (two_stage || pools) {
-            if (ix->fast_skip > 0) --ix->fast_skip; // (a recent call flagged too much for the fast scan to pay: plain mode 1)
-            else ix->opt_margin = 3;
-        } else if ((double)nq * (double)ix->ntotal * (double)ix->ld >= 1.5e12 && (ix->plane > 0 ? ix->plane : ix->ld) <= 1024) {
-            // a scan of milliseconds (half of BASELINE config 2 and up): the handful of launches of the stream-ordered
-            // certificate -- tens of microseconds when nothing is flagged -- is below 1 % of it, so large searches are
-            // exact without a caveat by default (split-tail searches: on the tail stream).  Nobody asked for it, so it may
-            // not cost much either (one pass over the index per 8 flagged queries costs as much as ~600 queries of the bf16
-            // scan: +14 % on a 4096-query search): up to nq / 512 flagged queries, at least 8 and at most 16 -- one or two
-            // passes -- are settled; a search that flags more (near-duplicate-heavy data, floods of ties) keeps its first
-            // results and counts them, as mode 1 always did.  "margin_check" = 3 lifts the budget to 1024.
-            ix->opt_margin = 3;
-            ix->resolve_budget = (int)std::max<int64_t>(8, std::min<int64_t>(16, nq / 512));
         }
     }
     if (!done) {
@@ -1774,36 +1831,48 @@ int mips_search_fused(mips_index_t* ix, const void* q_device, int q_dtype, int64
     if (!q_device || !out_idx_device || !out_scores_device) return fail(MIPS_E_INVALID, "mips_search_fused: NULL buffer");
     DeviceGuard g(ix->device);
     hipStream_t st = (hipStream_t)hip_stream;
-    if (tiny_eligible(ix, nq, k_fetch)) {
+    {   // (both forms below touch the index's scratch: an earlier scan error is reported, and a call on another stream ordered,
+        // before anything is enqueued)
         const int prev = take_scan_error(ix, "mips_search_fused");
         if (prev) return prev;
-        ORDER_ON(ix, st);
-        ix->call_metric = ix->metric;
-        if (ix->call_metric == MIPS_METRIC_L2) {
-            int rc = compute_phi(ix, st);
+    }
+    ORDER_ON(ix, st);
+    {
+        MarginScope margin_scope(ix, /*out_dev=*/true);
+        const bool certifies = ix->opt_margin >= 2;
+        if (tiny_eligible(ix, nq, k_fetch, certifies)) {
+            ix->call_metric = ix->metric;
+            if (ix->call_metric == MIPS_METRIC_L2) {
+                int rc = compute_phi(ix, st);
+                if (rc) return rc;
+            }
+            const bool stream_ordered = ix->opt_margin == 3;
+            int rc = tiny_search(ix, q_device, q_dtype, nq, k_fetch, k, normalize, ignore_device, out_scores_device, out_idx_device, false,
+                                 idx_offset, st, stream_ordered);
             if (rc) return rc;
+            if (stream_ordered) // certified without a synchronisation: the exact pass behind the one launch (it leaves at once when
+                                // nothing was flagged) ranks the hits of a flagged query and applies the same ignore filter
+                return resolve_flagged(ix, nq, k_fetch, out_scores_device, out_idx_device, false, idx_offset, st, false, /*skip_compact=*/true,
+                                       ignore_device, k);
+            if (ix->opt_margin != 2) return MIPS_OK;
+            if (!ix->nflag_host) HIP_TRY(hipHostMalloc((void**)&ix->nflag_host, 64, hipHostMallocDefault));
+            HIP_TRY(hipMemcpyAsync(ix->nflag_host, ix->last_nflag_dev, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            ix->last_flagged = (int64_t)ix->nflag_host[0];
+            if (ix->last_flagged == 0) return MIPS_OK;
+            // a flagged query: the unfused path below certifies it
         }
-        int rc = tiny_search(ix, q_device, q_dtype, nq, k_fetch, k, normalize, ignore_device, out_scores_device, out_idx_device, false,
-                             idx_offset, st);
-        if (rc) return rc;
-        if (ix->opt_margin != 2) return MIPS_OK;
-        if (!ix->nflag_host) HIP_TRY(hipHostMalloc((void**)&ix->nflag_host, 64, hipHostMallocDefault));
-        HIP_TRY(hipMemcpyAsync(ix->nflag_host, ix->last_nflag_dev, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        ix->last_flagged = (int64_t)ix->nflag_host[0];
-        if (ix->last_flagged == 0) return MIPS_OK;
-        // a flagged query: the unfused path below certifies it
     }
     // general form: the same steps as separate launches
     const void* qsrc = q_device;
-    if (normalize) {
+    if (normalize) { // (a buffer of its own: the searches' scratch -- qf32 / qf32b -- is rewritten by the nested call)
         const size_t qbytes = (size_t)nq * ix->d * sizeof(float);
-        int rc = ix->qf32b.ensure(qbytes); // (free on every index but the fp32-exact one during a re-scan, which this is not)
+        int rc = ix->qnorm.ensure(qbytes);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(ix->qf32b.p, q_device, qbytes, hipMemcpyDeviceToDevice, st));
-        rc = mips_l2_normalize((float*)ix->qf32b.p, nq, ix->d, ix->device, hip_stream);
+        HIP_TRY(hipMemcpyAsync(ix->qnorm.p, q_device, qbytes, hipMemcpyDeviceToDevice, st));
+        rc = mips_l2_normalize((float*)ix->qnorm.p, nq, ix->d, ix->device, hip_stream);
         if (rc) return rc;
-        qsrc = ix->qf32b.p;
+        qsrc = ix->qnorm.p;
     }
     if (!ignore_device)
         return mips_search(ix, qsrc, q_dtype, nq, k, out_scores_device, out_idx_device, idx_offset, MIPS_Q_DEVICE | MIPS_OUT_DEVICE, hip_stream);
@@ -1957,8 +2026,11 @@ int mips_index_set_param(mips_index_t* ix, const char* name, int64_t value) {
         ix->opt_f32_fast = (int)value;
         ix->fast_skip = 0;
     } else if (n == "margin_check") {
-        if (value < 0 || value > 3) return fail(MIPS_E_INVALID, "mips_index_set_param: margin_check must be 0, 1, 2 or 3");
+        if (value < 0 || value > 4) return fail(MIPS_E_INVALID, "mips_index_set_param: margin_check must be 0, 1, 2, 3 or 4");
         ix->opt_margin = (int)value;
+    } else if (n == "resolve_budget") {
+        if (value < 0) return fail(MIPS_E_INVALID, "mips_index_set_param: resolve_budget must be >= 0");
+        ix->resolve_budget = (int)std::min<int64_t>(value, mips::RESOLVE_MAX);
     } else if (n == "spin_limit") ix->opt_spin_limit = (int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 30));
     else if (n == "sub") {
 #ifdef MIPS_EXPERIMENTAL
@@ -1977,6 +2049,8 @@ int mips_index_check_error(mips_index_t* ix, int synchronize, void* hip_stream) 
     if (synchronize) {
         DeviceGuard g(ix->device);
         HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+        for (int e = 0; e < 2; ++e) // split-tail searches raise the sticky word from their tail stream
+            if (ix->tail_pending[e]) HIP_TRY(hipEventSynchronize(ix->tail_done[e]));
     }
     return take_scan_error(ix, "mips_index_check_error");
 }
@@ -1986,6 +2060,10 @@ const char* mips_index_last_kernel(const mips_index_t* ix) { return ix ? ix->las
 int mips_index_margin_stats(mips_index_t* ix, int64_t* flagged, int64_t* rescanned, int64_t* unresolved, int synchronize,
                             void* hip_stream) {
     if (!ix) return fail(MIPS_E_INVALID, "mips_index_margin_stats: index is NULL");
+    if (synchronize && ix->tail_pending[ix->cur_set]) { // a split-tail search writes its counters on the tail stream
+        DeviceGuard g(ix->device);
+        HIP_TRY(hipEventSynchronize(ix->tail_done[ix->cur_set]));
+    }
     if (ix->last_flagged < 0 && synchronize && ix->first_nflag_dev != nullptr) {
         // the last search re-scanned its flagged queries on the stream: first count = flagged = re-scanned, second = unresolved
         DeviceGuard g(ix->device);

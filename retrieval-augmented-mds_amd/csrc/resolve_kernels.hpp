@@ -53,6 +53,10 @@ struct ResolveArgs {
     int64_t* out_i;
     int64_t* out_packed;  // or [nq][k][2]
     unsigned* unresolved; // counter (zeroed by the host)
+    // the ignore filter of Mips.search (sotasum/mips.py:388-398) when the search that flagged was the fused hook call: the
+    // k (= k_out + 1) ranked hits lose the one equal to ignore[q] and are cut to k_out; output rows are k_out wide
+    const int64_t* ignore = nullptr;
+    int k_out = 0;        // 0: no filter, rows are k wide
 };
 
 template <bool L2>
@@ -178,8 +182,19 @@ __global__ __launch_bounds__(64) void resolve_finalize_kernel(ResolveArgs a) {
         const int oi = __shfl(id, t);
         rank += ranks_before(ok, oi, key, id) ? 1 : 0;
     }
-    if (lane < c && rank < a.k) {
-        const size_t o = (size_t)q * a.k + rank;
+    int pos = rank, width = a.k;
+    bool keep = lane < c && rank < a.k;
+    if (a.ignore != nullptr) { // (ids are unique: at most one hit is the banned one)
+        const int64_t banned = a.ignore[q];
+        const unsigned long long bb = __ballot(keep && (int64_t)id + a.idx_offset == banned);
+        const int rb = bb != 0ull ? __shfl(rank, __ffsll((long long)bb) - 1) : 0x7fffffff;
+        width = a.k_out;
+        keep = keep && rank != rb;
+        pos = rank - (rank > rb ? 1 : 0);
+        keep = keep && pos < width;
+    }
+    if (keep) {
+        const size_t o = (size_t)q * width + pos;
         if (a.out_packed) {
             a.out_packed[2 * o] = (int64_t)__float_as_uint(outv);
             a.out_packed[2 * o + 1] = (int64_t)id + a.idx_offset;
@@ -190,11 +205,10 @@ __global__ __launch_bounds__(64) void resolve_finalize_kernel(ResolveArgs a) {
     }
 }
 
-// flagged / unresolved counts of this search into host-visible words (read without synchronising by the NEXT search on
-// the index: a search that could not resolve everything switches the optimistic scans off for a while)
-__global__ void publish_resolve_stats_kernel(const int* n_dev, const unsigned* unresolved, unsigned* host_words) {
-    __hip_atomic_store(&host_words[0], (unsigned)*n_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&host_words[1], *unresolved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// The fall-back re-scan behind the exact pass (mips_hip.hip, rescan_on_stream with a gate): if it ran (gated count > 0), the
+// queries IT still flags on true K' = 32 lists are what this search leaves unresolved.
+__global__ void adopt_rescan_count_kernel(const int* gated_n, const unsigned* rescan_still_flagged, unsigned* unresolved) {
+    if (*gated_n > 0) *unresolved = *rescan_still_flagged;
 }
 
 } // namespace mips

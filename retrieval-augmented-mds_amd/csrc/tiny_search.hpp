@@ -55,6 +55,18 @@ struct TinyArgs {
     int64_t* out_i;
     int64_t* out_packed;   // or the packed all-gather payload [nq][k_out][2]
     int force_slow;        // test knob ("tiny" = 2): take the fall-back paths (pop selection, sequential re-score) everywhere
+    // fp32-exact index (template F32): docs = bf16(x) alone at the bf16 kernels' row pitch ld (mips_index::rows_hi, stage 1 of the
+    // two-stage search), rows_f32 = the fp32 rows [capacity][plane] the exact re-score runs on; the margin check is widened by
+    // the representation error |x - bf16 x| |q| + |bf16 x| |q - bf16 q| (m.dres2; |q - bf16 q|^2 is computed here)
+    const float* rows_f32;
+    int plane;
+    // stream-ordered certification (resolve_kernels.hpp): the last workgroup writes the flagged queries' numbers + count, clears
+    // the hit counters and -- only when something was flagged -- copies the staged queries to global memory for the exact pass
+    int* res_ids;          // [nq] or nullptr (no hand-off)
+    int* res_cnt;
+    int* res_hit_n;        // [>= 16]
+    unsigned* res_unres;
+    void* q_out;           // [nq][ld] bf16 (pitch ld) or, F32, [nq][plane] float32
 #ifdef MIPS_EXPERIMENTAL
     unsigned long long* dbg; // [gridDim.x][16] phase time stamps (100 MHz), or nullptr
 #endif
@@ -74,8 +86,10 @@ constexpr int TINY_WL = TINY_LISTS * TINY_KL;    // 192 candidates per (query, w
 constexpr int TINY_MAX_WG = 256;                 // one per CU; the final selection holds 8 x 256 / 64 = 32 candidates per lane
 
 // dynamic LDS of the kernel for row pitch ld
-constexpr int tiny_lds_bytes(int ld) {
+constexpr int tiny_lds_bytes(int ld, int plane = 0) {
     return 16 * ld * 2                 // staged queries
+           + 16 * 4 + 16 + 16 * 8 + 64 // margin flags, their count, |q - bf16 q|^2, the final level's bound
+           + 16 * plane * 4            // fp32-exact index: the staged queries as float32
            + 2 * 16 * TINY_WL * 4      // lane lists (scores, ids)
            + 2 * TINY_WAVES * 64 * 4   // survivors of the threshold test, per wave
            + 2 * 16 * TINY_POOL * 4    // cand, cand_s
@@ -102,6 +116,9 @@ constexpr int tiny_lds_bytes(int ld) {
 //   quad_perm(1,0,3,2) = lane ^ 1, quad_perm(2,3,0,1) = lane ^ 2, row_half_mirror = 7 - lane within 8, row_mirror =
 //   15 - lane within 16: after the four steps every lane of a 16-lane row holds the row's reduction (commutative ops).
 constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+// row_shr:1 (lane l reads lane l - 1 of its 16-lane row) and row_ror:9 (lane l reads lane (l - 9) mod 16): together they rotate
+// a value through the 8 lanes of a group -- sub -> sub + 1 for sub < 7, 7 -> 0 (tiny_seq_dot_f32)
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_ROR9 = 0x129;
 template <int CTRL>
 __device__ __forceinline__ unsigned tiny_dpp(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
@@ -135,9 +152,12 @@ __device__ __forceinline__ float tiny_wave_max(float v) { // every lane gets the
 // general pop selection (merge_select_body).  lb = this lane's share of the bound on what EARLIER levels excluded.
 // Writes out_i[0..8) (+ out_s), pads (-inf, IDX_NONE), and *out_bnd exactly as merge_select_body does.
 // All loads are issued before the first use (clamped addresses instead of predicated loads: no branch per load).
+// out_bnd2 != nullptr: the two parts of the bound go to two words -- *out_bnd = what EARLIER levels excluded (lb), *out_bnd2 =
+// the last pool member's score (what THIS level excluded) -- for the fp32-exact index, where the two are scores of different
+// accuracy (MFMA scores of bf16 operands / refined fp32 scores) and the margin check prices them differently.
 template <int LL, int NH, int NC>
 __device__ __forceinline__ bool tiny_select8(const float* cs, const int* ci, int nlist, float lb, float* surv_s, int* surv_i, int lane,
-                                             float* out_s, int* out_i, float* out_bnd) {
+                                             float* out_s, int* out_i, float* out_bnd, float* out_bnd2 = nullptr) {
     const int ncand = nlist * LL;
     float sv[NC];
     int iv[NC];
@@ -238,7 +258,14 @@ __device__ __forceinline__ bool tiny_select8(const float* cs, const int* ci, int
             const unsigned long long b7 = __ballot(lane < count && rank == TINY_POOL - 1);
             s7 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ms), __ffsll((long long)b7) - 1));
         }
-        if (lane == 0) *out_bnd = fmaxf(s7, lb);
+        if (lane == 0) {
+            if (out_bnd2 != nullptr) {
+                *out_bnd = lb;
+                *out_bnd2 = s7;
+            } else {
+                *out_bnd = fmaxf(s7, lb);
+            }
+        }
     }
     __builtin_amdgcn_wave_barrier();
     return true;
@@ -306,7 +333,50 @@ __device__ __forceinline__ float tiny_lb(const float* pb, int npre, int lane) {
     return lb;
 }
 
-template <bool L2>
+// The canonical score on fp32 operands: the SEQUENTIAL fp64 sum of the (exact) products, which rounds at nearly every step -- no
+// re-association is the same number, so the parallel-sum certificate of the bf16 path (tiny_cert_ok) has nothing to offer here.
+// Eight lanes per pair still load the row coalesced (lane `sub` owns 16-byte chunks sub, sub + 8, ...: one memory round trip
+// for the whole row), and the ONE live accumulator travels through them in column order: at step (t, s) lane s adds its
+// chunk t (four FMAs, in order) and hands the sum to lane s + 1 by DPP (7 -> 0 with row_ror:9).  Every lane executes every step
+// on whatever it holds -- only the live lane's value is ever read.  768 columns = 192 steps of 4 dependent v_fma_f64 + 2 DPP
+// moves, ~4 us, two waves per SIMD filling each other's latency.  x: global or LDS (generic), y: LDS.  Result on sub == 0.
+__device__ __forceinline__ double tiny_seq_dot_f32(const float* x, const float* y, int nchunk, int sub) {
+    double acc = 0.0;
+    u32x4 xr[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if (8 * t < nchunk) xr[t] = *reinterpret_cast<const u32x4*>(x + (sub + 8 * t) * 4);
+#pragma unroll 1
+    for (int h0 = 0; h0 < nchunk; h0 += 64) { // groups of 64 chunks = 256 columns: a LOOP (code size, see the staging comment)
+        u32x4 xn[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (h0 + 64 + 8 * t < nchunk) xn[t] = *reinterpret_cast<const u32x4*>(x + (h0 + 64 + sub + 8 * t) * 4);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (h0 + 8 * t < nchunk) { // (uniform)
+                const u32x4 yv = *reinterpret_cast<const u32x4*>(y + (h0 + sub + 8 * t) * 4);
+                double xd[4], yd[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xd[e] = (double)__uint_as_float(xr[t][e]);
+                    yd[e] = (double)__uint_as_float(yv[e]);
+                }
+#pragma unroll
+                for (int st = 0; st < 8; ++st) {
+                    double tmp = acc;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tmp = __builtin_fma(xd[e], yd[e], tmp); // (the product is exact in fp64: one rounding, as "acc += x * y")
+                    acc = st == 7 ? tiny_dpp<DPP_ROW_ROR9>(tmp) : tiny_dpp<DPP_ROW_SHR1>(tmp);
+                }
+            }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) xr[t] = xn[t];
+    }
+    return acc;
+}
+
+template <bool L2, bool F32>
 __global__ __launch_bounds__(TINY_THREADS, 1) void tiny_search_kernel(TinyArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* qs = reinterpret_cast<uint16_t*>(smem);                            // [16][ld] staged queries
@@ -321,7 +391,12 @@ __global__ __launch_bounds__(TINY_THREADS, 1) void tiny_search_kernel(TinyArgs a
     double* dots = reinterpret_cast<double*>(res_i + 16 * 8);                    // [16][TINY_POOL]
     double* qq_s = dots + 16 * TINY_POOL;                                        // [16]
     float* bnd_s = reinterpret_cast<float*>(qq_s + 16);                          // [16] what the final pool may have excluded
-    double* xmax2_s = reinterpret_cast<double*>(bnd_s + 16);                     // [1] copy of *m.xmax2 (loaded up front)
+    double* xmax2_s = reinterpret_cast<double*>(bnd_s + 16);                     // [2] copies of *m.xmax2, *m.dres2 (loaded up front)
+    unsigned char* flag_s = reinterpret_cast<unsigned char*>(xmax2_s + 2);       // [16] margin flags of the queries (64 bytes reserved)
+    int* nfl_s = reinterpret_cast<int*>(flag_s + 64);                            // [1] their count (16 bytes reserved)
+    double* qerr2_s = reinterpret_cast<double*>(flag_s + 80);                    // [16] |q - bf16 q|^2 (F32)
+    float* bnd2_s = reinterpret_cast<float*>(qerr2_s + 16);                      // [16] the final level's own bound (F32; 64 bytes)
+    float* qf = bnd2_s + 16;                                                     // [16][plane] staged queries as float32 (F32)
     __shared__ int is_last;
 
     const int tid = threadIdx.x;
@@ -350,8 +425,11 @@ __global__ __launch_bounds__(TINY_THREADS, 1) void tiny_search_kernel(TinyArgs a
     }
 
     TINY_STAMP(1);
-    double xm = 0.0;
-    if (tid == 0 && a.m.nflag != nullptr) xm = *a.m.xmax2; // (margin check: the load travels with the documents)
+    double xm = 0.0, xres = 0.0;
+    if (tid == 0 && a.m.nflag != nullptr) {
+        xm = *a.m.xmax2; // (margin check: the load travels with the documents)
+        if (F32) xres = *a.m.dres2;
+    }
     // ---- stage the queries: wave w takes rows w and w + 8, one wave per row and the same per-lane order of the sum of
     // squares as mips_l2_normalize; the row's loads are in flight together with the documents (one memory round trip).
     // Written for FEW INSTRUCTIONS, like everything below: this kernel runs every line of its code once, from a cold
@@ -397,9 +475,19 @@ __global__ __launch_bounds__(TINY_THREADS, 1) void tiny_search_kernel(TinyArgs a
         for (int j = 0; j < 16; ++j)
             if (j < nfull) dst[64 * j] = f32_to_bf16_rne(xv[j] * inv);
         for (int t = tt; t < a.ld; t += 64) qs[r * a.ld + t] = t < a.d ? f32_to_bf16_rne(xt * inv) : (uint16_t)0; // tail, padding
+        if (F32) { // the same rows as float32 (what mips_l2_normalize leaves / the caller's values): operands of the exact re-score
+            float* dstf = qf + r * a.plane + lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j < nfull) dstf[64 * j] = xv[j] * inv;
+            for (int t = tt; t < a.plane; t += 64) qf[r * a.plane + t] = t < a.d ? xt * inv : 0.f;
+        }
     }
     TINY_STAMP(3);
-    if (tid == 0) *xmax2_s = xm;
+    if (tid == 0) {
+        xmax2_s[0] = xm;
+        xmax2_s[1] = xres;
+    }
     __syncthreads();
     TINY_STAMP(4);
 
@@ -462,7 +550,8 @@ __global__ __launch_bounds__(TINY_THREADS, 1) void tiny_search_kernel(TinyArgs a
         if (lane < TINY_LISTS && ci[lane * TINY_KL + TINY_KL - 1] != IDX_NONE) lb = cs[lane * TINY_KL + TINY_KL - 1];
         bool ok = false;
         if (!a.force_slow)
-            ok = tiny_select8<TINY_KL, 1, TINY_WL / 64>(cs, ci, TINY_LISTS, lb, surv_s + wave * 64, surv_i + wave * 64, lane, gps + o, gpi + o,
+            ok = tiny_select8<TINY_KL, 1, TINY_WL / 64>(cs, ci, TINY_LISTS, lb, surv_s + wave * 64, surv_i + wave * 64, lane,
+                                                         F32 ? cand_s + q * TINY_POOL : gps + o, F32 ? cand + q * TINY_POOL : gpi + o,
                                                          &gbnd[(size_t)q * nwg + blockIdx.x]);
         if (!ok) {
             MergeArgs mw = a.m;
@@ -474,10 +563,49 @@ __global__ __launch_bounds__(TINY_THREADS, 1) void tiny_search_kernel(TinyArgs a
             mw.npre = 0;
             mw.bnd = nullptr;
             merge_select_body<TINY_POOL>(mw, cand, q, lane, cand_s, &gbnd[(size_t)q * nwg + blockIdx.x]);
-            if (lane < TINY_POOL) {
+            if (!F32 && lane < TINY_POOL) {
                 gps[o + lane] = cand_s[q * TINY_POOL + lane];
                 gpi[o + lane] = cand[q * TINY_POOL + lane];
             }
+        }
+        if (F32) {
+            // fp32-exact index: the workgroup's 8 candidates leave with REFINED scores -- fp32 rows x fp32 query, summed in fp64
+            // (any order: an approximation good to 2^-24 relative once stored as float32) -- instead of the MFMA scores of the
+            // bf16-rounded operands (2^-9).  The final level then ranks the workgroups' candidates by scores that differ from the
+            // canonical ones by rounding only, so what IT excludes needs a margin of 2^-23 |q| max|x|, not the representation error;
+            // what the workgroups excluded by MFMA score (gbnd) lies hundreds of ranks below the top and can afford the wide margin.
+            // 8 lanes per candidate, the whole row in flight in one memory round trip.
+            __builtin_amdgcn_wave_barrier();
+            const int pr = lane >> 3, sub = lane & 7;
+            const int id = cand[q * TINY_POOL + pr];
+            const float* x = a.rows_f32 + (size_t)(id != IDX_NONE ? id : 0) * a.plane;
+            const float* y = qf + (size_t)q * a.plane;
+            double acc = 0.0;
+            for (int ch = sub; ch < a.plane / 4; ch += 8) {
+                const u32x4 xv = *reinterpret_cast<const u32x4*>(x + ch * 4);
+                const u32x4 yv = *reinterpret_cast<const u32x4*>(y + ch * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc += (double)__uint_as_float(xv[e]) * (double)__uint_as_float(yv[e]);
+            }
+            acc += tiny_dpp<DPP_XOR1>(acc);
+            acc += tiny_dpp<DPP_XOR2>(acc);
+            acc += tiny_dpp<DPP_HALF_MIRROR>(acc);
+            const float rs = id != IDX_NONE ? (float)acc : -INFINITY;
+            float* sv = surv_s + wave * 64;
+            int* si = surv_i + wave * 64;
+            if (sub == 0) {
+                sv[pr] = rs;
+                si[pr] = id;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < TINY_POOL) { // re-sort by the refined score: the final level expects every list best first
+                int rank = 0;
+#pragma unroll
+                for (int t = 0; t < TINY_POOL; ++t) rank += ranks_before(sv[t], si[t], sv[lane], si[lane]) ? 1 : 0;
+                gps[o + rank] = sv[lane];
+                gpi[o + rank] = si[lane];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
     TINY_STAMP(6);
@@ -504,6 +632,17 @@ __global__ __launch_bounds__(TINY_THREADS, 1) void tiny_search_kernel(TinyArgs a
     m.out_packed = nullptr;
     if (m.bnd != nullptr) m.bnd = bnd_s; // the bound travels from the selection to the margin check inside this workgroup
     m.xmax2 = xmax2_s;
+    if (m.flag != nullptr) m.flag = flag_s; // (the flags stay in this workgroup too: the hand-off below reads them)
+    if (F32) {
+        m.dres2 = xmax2_s + 1;
+        m.qerr2 = qerr2_s;
+        if (m.bnd != nullptr) {
+            m.bnd2 = bnd2_s;
+            m.err_c2 = 1.1920928955078125e-07; // refined (fp64-summed, float32-stored) against canonical scores: rounding only
+        }
+        if (tid < 16) bnd2_s[tid] = -INFINITY; // (the fall-back selection reports one combined bound through m.bnd)
+        __syncthreads();
+    }
     if (tid == 0) {
         *a.ticket = 0u;                    // ready for the next launch on this stream
         if (m.nflag) *m.nflag = 0u;        // this call's flag counter
@@ -519,14 +658,38 @@ __global__ __launch_bounds__(TINY_THREADS, 1) void tiny_search_kernel(TinyArgs a
             float* sv_s = surv_s + wave * 64;
             int* sv_i = surv_i + wave * 64;
             float* bo = m.bnd != nullptr ? &m.bnd[q] : nullptr;
+            float* bo2 = F32 && m.bnd != nullptr ? &bnd2_s[q] : nullptr;
             const float* pb = m.pre_bnd + (size_t)q * m.npre;
-            if (nwg <= 64) ok = tiny_select8<TINY_POOL, 1, 8>(cs, ci, nwg, tiny_lb<1>(pb, m.npre, lane), sv_s, sv_i, lane, nullptr, cand + q * TINY_POOL, bo);
-            else if (nwg <= 128) ok = tiny_select8<TINY_POOL, 2, 16>(cs, ci, nwg, tiny_lb<2>(pb, m.npre, lane), sv_s, sv_i, lane, nullptr, cand + q * TINY_POOL, bo);
-            else ok = tiny_select8<TINY_POOL, 4, 32>(cs, ci, nwg, tiny_lb<4>(pb, m.npre, lane), sv_s, sv_i, lane, nullptr, cand + q * TINY_POOL, bo);
+            if (nwg <= 64) ok = tiny_select8<TINY_POOL, 1, 8>(cs, ci, nwg, tiny_lb<1>(pb, m.npre, lane), sv_s, sv_i, lane, nullptr, cand + q * TINY_POOL, bo, bo2);
+            else if (nwg <= 128) ok = tiny_select8<TINY_POOL, 2, 16>(cs, ci, nwg, tiny_lb<2>(pb, m.npre, lane), sv_s, sv_i, lane, nullptr, cand + q * TINY_POOL, bo, bo2);
+            else ok = tiny_select8<TINY_POOL, 4, 32>(cs, ci, nwg, tiny_lb<4>(pb, m.npre, lane), sv_s, sv_i, lane, nullptr, cand + q * TINY_POOL, bo, bo2);
         }
         if (!ok) merge_select_body<TINY_POOL>(m, cand, q, lane);
-        // |q|^2 of the staged row (L2 distances, margin check): sequential fp64 in the general path, same certificate here
-        {
+        if (F32) {
+            // |q - bf16 q|^2 (margin) and, for the inner-product metric, |q|^2 -- there it only enters the margin's error bound, so
+            // a parallel fp64 sum with a little slack serves (L2 needs the canonical |q|^2: the re-score loop below computes it)
+            const float* y = qf + (size_t)q * a.plane;
+            double aq = 0.0, ar = 0.0;
+            for (int ch = lane; ch < a.plane / 4; ch += 64) {
+                const u32x4 yv = *reinterpret_cast<const u32x4*>(y + ch * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ye = __uint_as_float(yv[e]);
+                    const double r = (double)ye - (double)bf16_bits_to_f32(f32_to_bf16_rne(ye));
+                    aq += (double)ye * (double)ye;
+                    ar += r * r;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                aq += __shfl_xor(aq, off);
+                ar += __shfl_xor(ar, off);
+            }
+            if (lane == 0) {
+                qerr2_s[q] = ar * (1.0 + 1e-12);
+                if (!L2) qq_s[q] = aq * (1.0 + 1e-12);
+            }
+        } else {
             const uint16_t* y = qs + (size_t)q * a.ld;
             double acc = 0.0;
             TinyCert ce = {0u, 0xffffffffu};
@@ -556,6 +719,25 @@ __global__ __launch_bounds__(TINY_THREADS, 1) void tiny_search_kernel(TinyArgs a
     __syncthreads();
     TINY_STAMP(8);
     // exact re-score: 8 lanes per (query, candidate) pair, 64 pairs per round
+    if (F32) { // on the fp32 rows (tiny_seq_dot_f32); L2 also needs the canonical |q|^2: nq more "pairs" (q, q)
+        const int npair = a.nq * TINY_POOL + (L2 ? a.nq : 0);
+#pragma unroll 1
+        for (int base = 0; base < npair; base += TINY_THREADS / 8) {
+            const int pair = base + (tid >> 3);
+            const int sub = tid & 7;
+            const bool inp = pair < npair;
+            const bool isqq = inp && pair >= a.nq * TINY_POOL;
+            const int qi = !inp ? 0 : isqq ? pair - a.nq * TINY_POOL : pair / TINY_POOL;
+            const int ci = !inp ? IDX_NONE : isqq ? 0 : cand[pair];
+            const float* y = qf + (size_t)qi * a.plane;
+            const float* x = isqq ? y : a.rows_f32 + (size_t)(ci != IDX_NONE ? ci : 0) * a.plane;
+            const double acc = tiny_seq_dot_f32(x, y, a.plane / 4, sub);
+            if (inp && sub == 0) {
+                if (isqq) qq_s[qi] = acc;
+                else if (ci != IDX_NONE) dots[pair] = acc;
+            }
+        }
+    } else
     for (int base = 0; base < a.nq * TINY_POOL; base += TINY_THREADS / 8) {
         const int pair = base + (tid >> 3);
         const int sub = tid & 7;
@@ -612,6 +794,31 @@ __global__ __launch_bounds__(TINY_THREADS, 1) void tiny_search_kernel(TinyArgs a
     }
     __syncthreads();
     TINY_STAMP(10);
+    // hand-off to the stream-ordered exact pass (resolve_kernels.hpp): what compact_flags_kernel does for the general path, and
+    // -- only when a query was flagged -- the staged queries in global memory, where exact_filter_kernel reads them
+    if (a.res_cnt != nullptr) {
+        if (tid == 0) {
+            int n = 0;
+            for (int q = 0; q < a.nq; ++q)
+                if (flag_s[q]) a.res_ids[n++] = q;
+            *a.res_cnt = n;
+            *a.res_unres = 0u;
+            *nfl_s = n;
+        }
+        if (tid < 16) a.res_hit_n[tid] = 0;
+        __syncthreads();
+        if (*nfl_s > 0) { // (uniform)
+            if (F32) {
+                u32x4* dst = reinterpret_cast<u32x4*>(a.q_out);
+                const u32x4* src = reinterpret_cast<const u32x4*>(qf);
+                for (int t = tid; t < a.nq * a.plane / 4; t += TINY_THREADS) dst[t] = src[t];
+            } else {
+                u32x4* dst = reinterpret_cast<u32x4*>(a.q_out);
+                const u32x4* src = reinterpret_cast<const u32x4*>(qs);
+                for (int t = tid; t < a.nq * a.ld / 8; t += TINY_THREADS) dst[t] = src[t];
+            }
+        }
+    }
     if (tid < a.nq) {
         const int q = tid;
         const int64_t banned = a.ignore ? a.ignore[q] : INT64_MIN;

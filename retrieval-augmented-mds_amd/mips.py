@@ -59,7 +59,10 @@ class MipsArgs:
     copy_forcing: float = 0.0
     doc_sep: str = " <DOC_SEP> "
     # backend knobs (not in the reference)
-    mips_index_dtype: str = "bf16"  # "bf16" (fast path) | "fp8_e4m3" | "f32" (fp32-exact: the reference's results on fp32 data)
+    # "f32" (default): fp32-exact -- the neighbours an fp32 brute force (FAISS IndexFlat, mips.py:552-560) returns on the
+    # caller's fp32 embeddings, which is what "drop-in" means.  "bf16" / "fp8_e4m3" store the rows rounded (2 / 1 B per
+    # element, the fastest scans) and are exact ON THE ROUNDED VALUES: explicit opt-ins for knowledge bases that tolerate it.
+    mips_index_dtype: str = "f32"
     mips_device: int = None
     mips_shard: bool = False  # under an initialised torch.distributed group: row-shard the index over the ranks
     #  instead of replicating it on every rank as lightning_model.py:180 does
@@ -119,11 +122,11 @@ def retriever_metrics(pred, counts) -> dict:
 
 
 def inner_product(x: np.ndarray, y: np.ndarray, k: int = 1, normalize: bool = True, device: int = None,
-                  dtype: str = "bf16"):
+                  dtype: str = "f32"):
     """Brute-force cross-check of mips.py:552-560, run on the GPU: optional row normalisation of
     both sides, exact top-k of x @ y.T.  Scores are descending; values are the canonical scores of
-    the operands as stored (dtype "bf16": rounded to bf16; "f32": the caller's fp32 values, i.e. the
-    reference's own arithmetic up to summation order)."""
+    the operands as stored (dtype "f32", the default: the caller's fp32 values, i.e. the reference's own
+    arithmetic up to summation order; "bf16": rounded to bf16 first -- an opt-in)."""
     import torch
 
     assert len(x.shape) == len(y.shape) == 2
@@ -215,11 +218,12 @@ class KnowledgeBase:
 
     def add_faiss_index(self, column: str, index_name: str = None, device: int = None, string_factory: str = None,
                         metric_type: int = None, custom_index=None, batch_size: int = 1000, train_size: int = None,
-                        faiss_verbose: bool = False, dtype: str = "bf16"):
+                        faiss_verbose: bool = False, dtype: str = "f32"):
         """HF Dataset.add_faiss_index as the reference calls it (retriever_lightning.py:395-404 / pretrain.py:
         470-479: `add_faiss_index(column="cls", index_name="mips_cls", metric_type=metric)`; mips.py:333-340 with
         string_factory / train_size / faiss_verbose).  Builds an exact MipsIndex over `self.columns[column]`
-        ([N, d'] float32).  metric_type None = faiss.IndexFlat's default (L2), as in HF.
+        ([N, d'] float32); dtype "f32" (default) = fp32-exact storage, the reference's neighbours on fp32 data.
+        metric_type None = faiss.IndexFlat's default (L2), as in HF.
           * inner product: the column is stored as it is;
           * L2: the reference only ever indexes phi-AUGMENTED vectors here (augment_xb, retriever_lightning.py:
             373-389): rows of constant norm sqrt(phi) whose last column is sqrt(phi - |x|^2).  The backend keeps

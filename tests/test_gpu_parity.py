@@ -22,6 +22,22 @@ def _index(x, metric=0):
     return ix
 
 
+def _stored(index):
+    """float32 values of the rows as the device holds them (bf16 / e4m3 storage up-cast, fp32-exact storage as it is)."""
+    raw = index.rows_raw()
+    if index.dtype == "bf16":
+        return synth.bf16_bits_to_f32(raw)
+    return raw if index.dtype == "f32" else synth.e4m3_bits_to_f32(raw)
+
+
+def _as_stored(index, q):
+    """what the index makes of float32 queries before it multiplies: rounded to its storage type, or left alone (fp32-exact)"""
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    if index.dtype == "bf16":
+        return synth.round_to_bf16(q)
+    return q if index.dtype == "f32" else synth.round_to_e4m3(q)
+
+
 def _check(ix, q, x, k, metric=0, brute=False, idx_offset=0):
     s, i = ix.search(q, k, idx_offset) if idx_offset else ix.search(q, k)
     fn = orc.search_exact_bruteforce if brute else orc.search_exact
@@ -229,25 +245,30 @@ def test_l2_normalize_kernel_and_max_norm():
     assert (xd[17] == 0).all()
 
 
+@pytest.mark.parametrize("dtype", [None, "bf16"])          # None = the facade's default: fp32-exact storage
 @pytest.mark.parametrize("metric,normalize", [(0, True), (0, False), (1, True)])
-def test_mips_facade_end_to_end(tmp_path, metric, normalize):
+def test_mips_facade_end_to_end(tmp_path, metric, normalize, dtype):
     n, d, k = 10000, 768, 5
     rng = np.random.default_rng(11)
     emb = (synth.generate(61, 0, n, d, synth.KIND_GAUSS) * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
     qs = synth.generate(62, 0, 8, d, synth.KIND_GAUSS)
     data = {"mips_column": [f"text {i}" for i in range(n)], "aid": [f"a{i}" for i in range(n)]}
     args = ram.MipsArgs(mips_topk=k, mips_metric_type=metric, mips_normalize=normalize,
-                        mips_tmp_folder=str(tmp_path), log_retriever_metrics=True)
+                        mips_tmp_folder=str(tmp_path), log_retriever_metrics=True, **({} if dtype is None else {"mips_index_dtype": dtype}))
+    assert ram.MipsArgs().mips_index_dtype == "f32"             # exact on the caller's fp32 values unless asked otherwise
     m = ram.Mips(args, data=data)
     m.build_index(emb)
     assert m.max_norm == pytest.approx(float(np.linalg.norm(emb.astype(np.float64), axis=1).max()), rel=1e-6)
     index = m.embeddings.get_index(m.index_name).faiss_index
-    stored = synth.bf16_bits_to_f32(index.rows_bf16())          # what the device actually holds
+    assert index.dtype == (dtype or "f32")
+    stored = _stored(index)                                      # what the device actually holds
     if normalize and metric == 0:
-        np.testing.assert_allclose(np.linalg.norm(stored, axis=1), 1.0, atol=2e-2)
+        np.testing.assert_allclose(np.linalg.norm(stored, axis=1), 1.0, atol=2e-2 if dtype == "bf16" else 1e-6)
+    elif dtype is None:
+        assert np.array_equal(stored, emb)                       # fp32-exact storage keeps the embeddings as they came
     pq = m._prepare_query(qs.copy())
     assert np.array_equal(pq, orc.prepare_query(qs.copy(), normalize, metric))
-    q_for_oracle = synth.round_to_bf16(pq[:, :d])
+    q_for_oracle = _as_stored(index, pq[:, :d])
     es, ei = orc.search_exact(q_for_oracle, stored, k, metric=metric)
     s, i = m.search(pq, k=k)
     assert np.array_equal(i, ei) and np.array_equal(s, es)
@@ -1043,8 +1064,8 @@ def test_np_search_is_inner_product_even_on_an_l2_index(tmp_path):
     m = ram.Mips(ram.MipsArgs(mips_metric_type=1, mips_normalize=False, mips_tmp_folder=str(tmp_path)))
     m.build_index(emb)
     s, i = m.np_search(qs, k)
-    stored = synth.bf16_bits_to_f32(m.embeddings.get_index(m.index_name).faiss_index.rows_bf16())
-    es, ei = orc.search_exact(synth.round_to_bf16(qs), stored, k, metric=orc.METRIC_INNER_PRODUCT)
+    stored = _stored(m.embeddings.get_index(m.index_name).faiss_index)
+    es, ei = orc.search_exact(_as_stored(m.embeddings.get_index(m.index_name).faiss_index, qs), stored, k, metric=orc.METRIC_INNER_PRODUCT)
     assert np.array_equal(i, ei) and np.array_equal(s, es) and (np.diff(s, axis=1) <= 0).all()
     s2, i2 = m.search(m._prepare_query(qs.copy()), k=k)          # the index itself still answers in L2
     assert (np.diff(s2, axis=1) >= 0).all() and np.array_equal(i2, ei)   # same neighbours (IP == augmented L2)
@@ -1191,9 +1212,10 @@ def test_scan_timeout_on_one_shard_reaches_every_rank():
 
 
 # ------------------------------------------------------------------ a9 / f4: the full-KB eval consumer, a10: in-batch scoring
+@pytest.mark.parametrize("dtype", [None, "bf16"])          # None = add_faiss_index's default: fp32-exact storage
 @pytest.mark.parametrize("d", [768, 1024])
 @pytest.mark.parametrize("inner_product", [False, True])
-def test_full_kb_eval_call_text(d, inner_product):
+def test_full_kb_eval_call_text(d, inner_product, dtype):
     """retriever_lightning.py:372-404 + 313-321 replayed against KnowledgeBase: phi-augment the `cls` column
     (default, L2) or keep it (inner_product=True), `add_faiss_index(column="cls", index_name="mips_cls",
     metric_type=metric)`, then `get_nearest_examples_batch("mips_cls", queries=augment_xq(q) | q, k=top_k)`."""
@@ -1204,14 +1226,14 @@ def test_full_kb_eval_call_text(d, inner_product):
     kb_cols = {"mips_column": [f"abstract {t}" for t in range(n)], "aid": [[f"a{t}", f"b{t % 7}"] for t in range(n)]}
     column, metric = orc.full_kb_eval_index(cls, inner_product)                 # what the reference puts into "cls"
     kb = ram.KnowledgeBase(dict(kb_cols, cls=column))
-    kb.add_faiss_index(column="cls", index_name="mips_cls", metric_type=metric)
+    kb.add_faiss_index(column="cls", index_name="mips_cls", metric_type=metric, **({} if dtype is None else {"dtype": dtype}))
     q = query_cls if inner_product else ram.augment_xq(query_cls)               # :313-315
     scores, examples = kb.get_nearest_examples_batch("mips_cls", queries=q, k=top_k)
     index = kb.get_index("mips_cls").faiss_index
-    assert index.d == d and index.metric_type == metric and index.ntotal == n
-    stored = synth.bf16_bits_to_f32(index.rows_bf16())
-    np.testing.assert_array_equal(stored, synth.round_to_bf16(cls))             # the augmentation column is not stored
-    es, ex = orc.nearest_examples_batch(lambda qq, kk: orc.search_exact(synth.round_to_bf16(qq[:, :d]), stored, kk, metric=metric),
+    assert index.d == d and index.metric_type == metric and index.ntotal == n and index.dtype == (dtype or "f32")
+    stored = _stored(index)
+    np.testing.assert_array_equal(stored, _as_stored(index, cls))               # the augmentation column is not stored
+    es, ex = orc.nearest_examples_batch(lambda qq, kk: orc.search_exact(_as_stored(index, qq[:, :d]), stored, kk, metric=metric),
                                         kb_cols, q, top_k)
     assert len(scores) == nq and all(np.array_equal(a, b) for a, b in zip(scores, es))
     assert [e["aid"] for e in examples] == [e["aid"] for e in ex]
@@ -1219,7 +1241,7 @@ def test_full_kb_eval_call_text(d, inner_product):
     if not inner_product:
         # the distances are those of brute force on the reference's augmented fp32 vectors (1e-3: bf16 storage)
         d2 = ((orc.augment_xq(query_cls).astype(np.float64)[:, None, :] - column.astype(np.float64)[None, :, :]) ** 2).sum(-1)
-        np.testing.assert_allclose(np.stack(scores), np.sort(d2, axis=1)[:, :top_k], rtol=2e-2)
+        np.testing.assert_allclose(np.stack(scores), np.sort(d2, axis=1)[:, :top_k], rtol=2e-2 if dtype == "bf16" else 1e-4)
         with pytest.raises(ValueError, match="not zero"):
             bad = q.copy()
             bad[0, -1] = 1.0
@@ -1269,13 +1291,13 @@ def test_inner_product_normalized_matches_reference_golden(golden_dir):
     """Golden G2: the REAL reference inner_product(..., normalize=True) on the config-1 shape."""
     g = np.load(os.path.join(golden_dir, "g1_g2_inner_product.npz"))
     x = synth.generate(int(g["seed_docs"]), 0, int(g["n"]), int(g["d"]), int(g["kind"]))
-    # fp32-exact index: the reference's neighbours and scores (the normalised rows are NOT bf16 values)
-    s32, i32 = ram.inner_product(g["queries"], x, k=int(g["k"]), normalize=True, dtype="f32")
+    # the default (fp32-exact index): the reference's neighbours and scores (the normalised rows are NOT bf16 values)
+    s32, i32 = ram.inner_product(g["queries"], x, k=int(g["k"]), normalize=True)
     assert np.array_equal(i32, g["indices_norm"])
     np.testing.assert_allclose(s32, g["scores_norm"], rtol=2e-6, atol=1e-7)
-    # default bf16 index: exact on the bf16-ROUNDED normalised rows (DESIGN.md section 7), so against the fp32
+    # bf16 storage, an explicit opt-in: exact on the bf16-ROUNDED normalised rows (DESIGN.md section 7), so against the fp32
     # reference a near-tie may legitimately swap; the neighbour SETS and the scores still agree closely
-    s, i = ram.inner_product(g["queries"], x, k=int(g["k"]), normalize=True)
+    s, i = ram.inner_product(g["queries"], x, k=int(g["k"]), normalize=True, dtype="bf16")
     assert np.array_equal(i[:, 0], g["indices_norm"][:, 0])
     same = [len(set(a) & set(b)) for a, b in zip(i.tolist(), g["indices_norm"].tolist())]
     assert min(same) >= int(g["k"]) - 1 and sum(same) >= 8 * int(g["k"]) - 2
@@ -1372,8 +1394,8 @@ def _facade_shard_worker(rank, world, port, tmp, ret):
             out1, out2 = whole.forward(qs.copy(), k=k), m.forward(qs.copy(), k=k)
             ok &= out1.examples == out2.examples and m.max_norm == whole.max_norm and m.phi == whole.phi
             # vs the oracle on the stored rows
-            stored = synth.bf16_bits_to_f32(whole.embeddings.get_index(m.index_name).faiss_index.rows_bf16())
-            es, ei = orc.search_exact(synth.round_to_bf16(pq[:, :d]), stored, k, metric=metric)
+            stored = _stored(whole.embeddings.get_index(m.index_name).faiss_index)
+            es, ei = orc.search_exact(_as_stored(whole.embeddings.get_index(m.index_name).faiss_index, pq[:, :d]), stored, k, metric=metric)
             ok &= np.array_equal(i2, ei) and np.array_equal(s2, es)
             # ---- collective build without the disk round trip, then a collective save read back by one process
             c = ram.Mips(ram.MipsArgs(mips_metric_type=metric, mips_normalize=normalize, mips_tmp_folder=folder + "c",
@@ -1489,12 +1511,19 @@ def test_near_duplicates_crowding_one_sub_list_are_certified(nq):
     s0, i0 = ix.search(q, k)
     assert np.array_equal(i0, i) and np.array_equal(s0, s) and ix.margin_stats()["rescanned"] == st["flagged"]
     ix.set_param("resolve", 1)
-    # device tensors: by default flagged queries are only COUNTED (nothing may synchronise) ...
+    # device tensors: certified by default as well -- WITHOUT a synchronisation (the exact pass is enqueued behind the scan) ...
     qd = torch.from_numpy(q).cuda()
+    ds, di = ix.search(qd, k)
+    assert ix.margin_stats() == st
+    assert np.array_equal(di.cpu().numpy()[stars], ei) and np.array_equal(ds.cpu().numpy()[stars], es)
+    assert np.array_equal(di.cpu().numpy()[free], fi) and np.array_equal(ds.cpu().numpy()[free], fs)
+    # ... "margin_check" = 4 only COUNTS the flagged queries (the first results stand) ...
+    ix.set_param("margin_check", 4)
     ds, di = ix.search(qd, k)
     st1 = ix.margin_stats()
     assert st1["flagged"] == st["flagged"] and st1["rescanned"] == 0 and st1["unresolved"] == st["flagged"]
-    # ... and certified on request
+    assert not np.array_equal(di.cpu().numpy()[stars], ei)   # (this case is built so that the uncertified first result is wrong)
+    # ... 2 certifies and synchronises to read the counts
     ix.set_param("margin_check", 2)
     ds, di = ix.search(qd, k)
     assert ix.margin_stats() == st
@@ -1594,8 +1623,8 @@ def test_margin_check_on_ordinary_data_flags_few_and_changes_nothing():
         st = ix.margin_stats()
         assert np.array_equal(i, ei) and np.array_equal(s, es)
         assert 0 <= st["flagged"] <= nq // 4 and st["rescanned"] == st["flagged"] and st["unresolved"] <= st["flagged"], (dtype, st)
-        ds, di = ix.search(torch.from_numpy(q).cuda(), k)      # counted only
-        assert np.array_equal(di.cpu().numpy(), ei) and ix.margin_stats()["flagged"] == st["flagged"]
+        ds, di = ix.search(torch.from_numpy(q).cuda(), k)      # device outputs: certified on the stream
+        assert np.array_equal(di.cpu().numpy(), ei) and ix.margin_stats() == st
     l2 = _index(x, metric=ram.METRIC_L2)
     s, i = l2.search(q, 10)                                    # K' = 16 first pass, L2 distances, rescan with K' = 32
     es, ei = orc.search_exact(q, x, 10, metric=orc.METRIC_L2)
@@ -1603,16 +1632,21 @@ def test_margin_check_on_ordinary_data_flags_few_and_changes_nothing():
 
 
 # ------------------------------------------------------------------ the reference's own call shape in one launch
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
 @pytest.mark.parametrize("n,nq,d,k,metric", [(10000, 8, 768, 5, 0), (33, 16, 768, 5, 0), (65536, 3, 1024, 6, 0), (4099, 16, 100, 1, 0),
                                                (10000, 8, 768, 5, 1), (3, 2, 64, 5, 0), (20011, 11, 512, 4, 1)])
-def test_tiny_search_is_the_general_path_in_one_launch(n, nq, d, k, metric):
-    """<= 16 queries on a small bf16 index take tiny_search_kernel (staging + MFMA scan + select + exact re-score in
-    ONE launch): bit-identical to the general path ("tiny" = 0) and to the oracle, NumPy and CUDA call shapes, packed
-    payload and row offsets included; the ticket of its last-workgroup hand-off survives repeated calls."""
+def test_tiny_search_is_the_general_path_in_one_launch(n, nq, d, k, metric, dtype):
+    """<= 16 queries on a small bf16 or fp32-exact index take tiny_search_kernel (staging + MFMA scan + select + exact
+    re-score in ONE launch): bit-identical to the general path ("tiny" = 0) and to the oracle, NumPy and CUDA call shapes,
+    packed payload and row offsets included; the ticket of its last-workgroup hand-off survives repeated calls.  The
+    fp32-exact index scans bf16(x) . bf16(q) and re-scores on the fp32 rows (sequential fp64, the canonical sum)."""
     x = synth.generate(251, 0, n, d, synth.KIND_GAUSS)
     q = synth.generate(252, 0, nq, d, synth.KIND_GAUSS)
+    if dtype == "f32":   # rows that are NOT bf16 values (the queries stay bf16 values: the bfloat16 call below is lossless)
+        x = (x * np.random.default_rng(n).uniform(0.5, 2.0, (n, 1))).astype(np.float32)
     es, ei = orc.search_exact(q, x, k, metric=metric, idx_offset=700)
-    ix = _index(x, metric=metric)
+    ix = ram.MipsIndex(d, metric=metric, dtype=dtype)
+    ix.add(x)
     qd = torch.from_numpy(q).cuda()
     for rep in range(3):
         s, i = ix.search(q, k, 700)
@@ -1630,6 +1664,14 @@ def test_tiny_search_is_the_general_path_in_one_launch(n, nq, d, k, metric):
     gs, gi = ix.search(qd, k, 700)
     assert not ix.last_kernel.startswith("mips::tiny") and torch.equal(gi, di) and torch.equal(gs, ds)
     assert ix.margin_stats()["flagged"] == st["flagged"]          # the same queries are flagged by either path
+    if dtype == "f32":   # queries that are not bf16 values either
+        q2 = (q * np.random.default_rng(nq).uniform(0.5, 2.0, (nq, 1))).astype(np.float32)
+        es2, ei2 = orc.search_exact(q2, x, k, metric=metric)
+        ix.set_param("tiny", 1)
+        s2, i2 = ix.search(torch.from_numpy(q2).cuda(), k)
+        assert ix.last_kernel.startswith("mips::tiny_search_kernel") and ix.last_kernel.endswith("true>")
+        assert np.array_equal(i2.cpu().numpy(), ei2) and np.array_equal(s2.cpu().numpy(), es2)
+        assert ix.margin_stats()["unresolved"] == 0
 
 
 def test_tiny_search_ties_and_stream_of_calls():
@@ -1694,18 +1736,20 @@ def test_tiny_search_fallback_paths(metric):
         assert np.array_equal(i, ei) and np.array_equal(s, es)
 
 
+@pytest.mark.parametrize("dtype", [None, "bf16"])          # None = the facade's default: fp32-exact storage
 @pytest.mark.parametrize("metric,normalize", [(0, True), (0, False), (1, True)])
-def test_fused_hook_search_prepare_search_ignore_in_one_call(tmp_path, metric, normalize):
+def test_fused_hook_search_prepare_search_ignore_in_one_call(tmp_path, metric, normalize, dtype):
     """Mips.search_device -> mips_search_fused: `_prepare_query` + `search` + the ignore filter of mips.py:388-398 as
     one library call (one launch at B = 8, N = 10^4): equal to the separate device steps and to the oracle."""
     n, d, k, b = 10000, 768, 5, 8
     rng = np.random.default_rng(3)
     emb = (synth.generate(261, 0, n, d, synth.KIND_GAUSS) * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
     qs = (synth.generate(262, 0, b, d, synth.KIND_GAUSS) * rng.uniform(0.5, 2.0, (b, 1))).astype(np.float32)
-    m = ram.Mips(ram.MipsArgs(mips_metric_type=metric, mips_normalize=normalize, mips_tmp_folder=str(tmp_path)))
+    m = ram.Mips(ram.MipsArgs(mips_metric_type=metric, mips_normalize=normalize, mips_tmp_folder=str(tmp_path),
+                              **({} if dtype is None else {"mips_index_dtype": dtype})))
     m.build_index(emb)
     index = m.embeddings.get_index(m.index_name).faiss_index
-    stored = synth.bf16_bits_to_f32(index.rows_bf16())
+    stored = _stored(index)
     qd = torch.from_numpy(qs).cuda()
     keep = qd.clone()
     # separate device steps (the round-1 form)
@@ -1719,9 +1763,11 @@ def test_fused_hook_search_prepare_search_ignore_in_one_call(tmp_path, metric, n
     s0, i0 = m.search_device(qd, k=k)
     assert torch.equal(i0, ri[:, :k]) and torch.equal(s0, rs[:, :k])
     # the oracle on what the device searched with
-    q_used = synth.round_to_bf16(qn.cpu().numpy())
+    q_used = _as_stored(index, qn.cpu().numpy())
     es, ei = orc.mips_search(lambda qq, kk: orc.search_exact(q_used, stored, kk, metric=metric), q_used, ignore.cpu().tolist(), k)
     assert [list(map(int, r)) for r in ei] == i.cpu().tolist()
+    assert np.array_equal(np.array(es, dtype=np.float32), s.cpu().numpy())
+    assert index.margin_stats()["unresolved"] == 0             # the hook's path is certified on the stream
     # larger batches take the same call through separate launches: same answers
     big = torch.cat([qd] * 5)[:33]
     s2, i2 = m.search_device(big, ignore_indexes=torch.cat([ignore] * 5)[:33], k=k)
@@ -1811,7 +1857,7 @@ def test_streaming_index_build_equals_one_shot_build(tmp_path, metric, normalize
         assert keep is None or torch.equal(batch, keep)            # the encoder's tensor is left alone
     st.end_index_build()
     i1, i2 = one._index(), st._index()
-    assert i2.ntotal == i1.ntotal == 6500 and np.array_equal(i1.rows_bf16(), i2.rows_bf16())
+    assert i2.ntotal == i1.ntotal == 6500 and i1.dtype == "f32" and np.array_equal(i1.rows_raw(), i2.rows_raw())
     assert st.max_norm == one.max_norm and st.phi == one.phi
     assert st.embeddings.columns["aid"] == data["aid"][:6500]
     pq = one._prepare_query(qs.copy())
@@ -1819,3 +1865,126 @@ def test_streaming_index_build_equals_one_shot_build(tmp_path, metric, normalize
     s2, j2 = st.search(pq, k=k)
     assert np.array_equal(j1, j2) and np.array_equal(s1, s2)
     assert st.forward(qs.copy(), k=k).examples == one.forward(qs.copy(), k=k).examples
+
+
+# ------------------------------------------------------------------ round 3: exact by default on the drop-in surface
+@pytest.mark.parametrize("case", ["g2_cfg1", "g1b_fp32"])
+def test_default_facade_returns_the_reference_neighbours(tmp_path, golden_dir, case):
+    """At DEFAULT MipsArgs (fp32-exact storage) the facade returns the REAL reference's neighbours index for index: golden G2
+    (BASELINE config 1: 10 000 x 768, 8 queries, inner_product(normalize=True)) and golden G1b (plain fp32 data that is not
+    bf16-representable), inner product on normalised rows and L2, host (NumPy) and device-resident (search_device: one
+    launch) call shapes, with and without `ignore_indexes` (sotasum/mips.py:368-400, 552-560)."""
+    if case == "g2_cfg1":
+        g = np.load(os.path.join(golden_dir, "g1_g2_inner_product.npz"))
+        docs = synth.generate(int(g["seed_docs"]), 0, int(g["n"]), int(g["d"]), int(g["kind"]))
+        qs, k = g["queries"], int(g["k"])
+    else:
+        g = np.load(os.path.join(golden_dir, "g1b_inner_product_f32.npz"))
+        docs, qs, k = g["y"], g["x"], 5                              # (the golden holds the top 10: its first 5 are the top 5)
+    nq = len(qs)
+    gold = {0: g["indices_norm"][:, :k], 1: g["indices_raw"][:, :k]}  # L2 on the phi-augmented rows ranks like the raw inner product
+    gold_s = {0: g["scores_norm"][:, :k], 1: g["scores_raw"][:, :k]}
+    for metric in (0, 1):
+        args = ram.MipsArgs(mips_metric_type=metric, mips_tmp_folder=str(tmp_path / f"m{metric}"))   # every other knob at its default
+        assert args.mips_index_dtype == "f32" and args.mips_normalize
+        m = ram.Mips(args)
+        m.build_index(docs)
+        index = m._index()
+        pq = m._prepare_query(qs.copy())
+        s, i = m.search(pq, k=k)
+        assert np.array_equal(i, gold[metric]), (case, metric)
+        if metric == 0:
+            np.testing.assert_allclose(s, gold_s[0], rtol=2e-6, atol=1e-7)
+        else:   # squared distances on the augmented vectors: |q|^2 + phi - 2 q.x
+            want = (qs.astype(np.float64) ** 2).sum(1)[:, None] + m.phi - 2.0 * gold_s[1].astype(np.float64)
+            np.testing.assert_allclose(s, want, rtol=1e-5)
+            assert (np.diff(s, axis=1) >= 0).all()
+        # ignore_indexes: the reference fetches k + 1, drops the banned id, keeps k
+        ban = [int(gold[metric][j][j % 2]) for j in range(nq)]
+        s2, i2 = m.search(pq, ignore_indexes=ban, k=k)
+        stored, q_used = _stored(index), _as_stored(index, pq[:, :docs.shape[1]])
+        es2, ei2 = orc.mips_search(lambda qq, kk: orc.search_exact(q_used, stored, kk, metric=metric), pq, ban, k)
+        assert [list(map(int, r)) for r in i2] == [list(map(int, r)) for r in ei2]
+        for j in range(nq):
+            assert [int(t) for t in i2[j][:k - 1]] == [int(t) for t in gold[metric][j] if int(t) != ban[j]][:k - 1]
+        # the device-resident hook (retriever_generator.py:143-153 without the .cpu() hop): same neighbours, certified, no sync
+        qd = torch.from_numpy(qs).cuda()
+        ds, di = m.search_device(qd, k=k)
+        assert index.last_kernel.startswith("mips::tiny_search_kernel") and index.last_kernel.endswith("true>")
+        st = index.margin_stats()
+        assert st["unresolved"] == 0 and st["rescanned"] == st["flagged"], st
+        assert np.array_equal(di.cpu().numpy(), gold[metric])
+        gs, gi = m.search_device(qd, ignore_indexes=torch.tensor(ban).cuda(), k=k)
+        assert gi.cpu().tolist() == [list(map(int, r)) for r in ei2] and index.margin_stats()["unresolved"] == 0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_hook_near_duplicates_are_certified_on_the_stream(tmp_path, dtype):
+    """The scoring hook's own call shape (B <= 16, Mips.search_device -> mips_search_fused -> ONE launch) on the adversarial
+    near-duplicate case: MFMA scores tie, the sub-lists keep the wrong copies, the margin check flags the query -- and the exact
+    pass enqueued behind the one-launch kernel (no synchronisation) returns the oracle's rows, with and without the ignore
+    filter.  `unresolved` stays 0."""
+    x, q, rows, stars = _near_duplicate_case(nq=16)
+    k = 5
+    m = ram.Mips(ram.MipsArgs(mips_normalize=False, mips_index_dtype=dtype, mips_tmp_folder=str(tmp_path)))
+    m.build_index(x)
+    index = m._index()
+    es, ei = orc.search_exact_bruteforce(q[stars], x, k + 1)
+    free = np.setdiff1d(np.arange(16), stars)
+    fs, fi = orc.search_exact(q[free], x, k + 1)
+    qd = torch.from_numpy(q).cuda()
+    for rep in range(3):
+        s, i = m.search_device(qd, k=k)
+    assert index.last_kernel.startswith("mips::tiny_search_kernel")
+    st = index.margin_stats()
+    assert st["flagged"] >= len(stars) and st["rescanned"] == st["flagged"] and st["unresolved"] == 0, st
+    i, s = i.cpu().numpy(), s.cpu().numpy()
+    assert np.array_equal(i[stars], ei[:, :k]) and np.array_equal(s[stars], es[:, :k])
+    assert np.array_equal(i[free], fi[:, :k]) and np.array_equal(s[free], fs[:, :k])
+    assert np.array_equal(i[stars], np.tile(rows[::-1][:k], (len(stars), 1)))    # the k HIGHEST-index copies, best first
+    # ban the best copy (star queries) / the second hit (the others): k + 1 fetched, filtered, cut to k -- by the exact pass too
+    ban = np.zeros(16, np.int64)
+    ban[stars] = ei[:, 0]
+    ban[free] = fi[:, 1]
+    s2, i2 = m.search_device(qd, ignore_indexes=torch.from_numpy(ban).cuda(), k=k)
+    st2 = index.margin_stats()
+    assert st2["flagged"] >= len(stars) and st2["unresolved"] == 0, st2
+    i2, s2 = i2.cpu().numpy(), s2.cpu().numpy()
+    assert np.array_equal(i2[stars], ei[:, 1:]) and np.array_equal(s2[stars], es[:, 1:])
+    assert np.array_equal(i2[free], np.delete(fi, 1, axis=1)) and np.array_equal(s2[free], np.delete(fs, 1, axis=1))
+    # "margin_check" = 4 (count only): the uncertified first result of this case is wrong -- which is why certifying is the default
+    index.set_param("margin_check", 4)
+    s4, i4 = m.search_device(qd, k=k)
+    st4 = index.margin_stats()
+    assert st4["flagged"] >= len(stars) and st4["rescanned"] == 0 and st4["unresolved"] == st4["flagged"]
+    if dtype == "bf16":   # (an fp32-exact index that may not certify scans hi.qhi + hi.qlo + lo.qhi with true lists instead)
+        assert st4["flagged"] == st["flagged"] and not np.array_equal(i4.cpu().numpy()[stars], ei[:, :k])
+    index.set_param("margin_check", 1)
+    # the host (NumPy) call of the same shape certifies as well
+    hs, hi = m.search(q, k=k)
+    assert np.array_equal(hi[stars], ei[:, :k]) and np.array_equal(hi[free], fi[:, :k])
+
+
+def test_hook_on_clustered_fp32_rows_returns_the_brute_force_neighbours(tmp_path):
+    """fp32 rows that bf16 cannot tell apart (clusters of 40 members within 1e-4 of each other), the hook's call shape on the
+    default fp32-exact index: the one-launch kernel scans bf16(x) . bf16(q), its widened margin flags what that cannot decide and
+    the stream-ordered exact pass settles it on the fp32 rows -- the result is the fp32 brute force's, bit for bit."""
+    rng = np.random.default_rng(5)
+    c = rng.standard_normal((300, 768)).astype(np.float32)
+    x = (np.repeat(c, 40, axis=0) * (1.0 + 1e-4 * rng.standard_normal((12000, 1)))).astype(np.float32)
+    x += (1e-4 * rng.standard_normal(x.shape)).astype(np.float32)
+    q = (c[rng.integers(0, 300, 16)] + 0.01 * rng.standard_normal((16, 768))).astype(np.float32)
+    for metric in (0, 1):
+        m = ram.Mips(ram.MipsArgs(mips_metric_type=metric, mips_normalize=False, mips_tmp_folder=str(tmp_path / str(metric))))
+        m.build_index(x)
+        es, ei = orc.search_exact(q, x, 5, metric=metric)
+        s, i = m.search_device(torch.from_numpy(q).cuda(), k=5)
+        index = m._index()
+        assert index.last_kernel.startswith("mips::tiny_search_kernel") and index.dtype == "f32"
+        st = index.margin_stats()
+        assert st["flagged"] > 0 and st["rescanned"] == st["flagged"] and st["unresolved"] == 0, st
+        assert np.array_equal(i.cpu().numpy(), ei) and np.array_equal(s.cpu().numpy(), es)
+        ban = torch.from_numpy(ei[:, 2].copy()).cuda()
+        s2, i2 = m.search_device(torch.from_numpy(q).cuda(), ignore_indexes=ban, k=4)
+        es5, ei5 = orc.search_exact(q, x, 5, metric=metric)
+        assert np.array_equal(i2.cpu().numpy(), np.delete(ei5, 2, axis=1)) and np.array_equal(s2.cpu().numpy(), np.delete(es5, 2, axis=1))
