@@ -56,7 +56,9 @@ def parse():
     ap.add_argument("--cpu-torch-queries", type=int, default=512, help="queries per repeat of the torch CPU baseline")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-regimes", action="store_true", help="skip the 2^24-row regime measurements (N = 1 only)")
+    ap.add_argument("--no-regimes", action="store_true", help="skip the extra regime measurements (2^24-row index; N > 1: BASELINE config 3 / 5 row-sharded)")
+    ap.add_argument("--regime-rows", type=int, default=0,
+                    help="N > 1: total rows of the row-sharded regime index (default 2^24 = BASELINE config 3 when --rows is the default, else 4 x --rows)")
     ap.add_argument("--index-dtype", default="bf16", choices=["bf16", "fp8_e4m3"],
                     help="fp8_e4m3 = BASELINE config 5 (index and queries quantised to OCP e4m3, fp8 MFMA)")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: run every step's all-gather + merge before the next scan")
@@ -184,6 +186,73 @@ def regime(ram, torch, rows, d, nq, k, dtype, device, iters):
     del ix
     torch.cuda.empty_cache()
     return out
+
+
+def regime_sharded(ram, torch, dist, rows, d, nq, k, dtype, local_rank, world, rank, steps, pipelined, coll_dev, dist_info):
+    """N > 1: BASELINE config 3 (config 5 with dtype fp8_e4m3) in the same run -- a `rows` x d index row-sharded over the ranks
+    (weak in nothing: the total is fixed, rank r keeps rows [r ceil(rows / N), ...)), Q queries replicated, every step = local
+    fused scan + ONE all-gather + replicated merge, all inside the timed region (barrier + synchronize on both sides, MAX over
+    ranks).  Reports the system rate and, per rank, shard size, scan-kernel time (HIP events) and MFMA fraction.  Collective:
+    every rank calls it."""
+    index = ram.ShardedMipsIndex(d, metric=ram.METRIC_IP, dtype=dtype, device=local_rank)
+    index.add_synthetic_global(rows, ram.SEED_DOCS, ram.SYNTH_GAUSS)
+    q = ram.synth_fill(nq, d, 0, ram.SEED_QUERIES, ram.SYNTH_GAUSS, dtype="bf16", device=local_rank)
+    local_rows = index.hi - index.lo
+
+    def run(count):
+        out = None
+        if pipelined:
+            prev = None
+            for _ in range(count):
+                cur = index.search_async(q, k)
+                if prev is not None:
+                    out = prev.result()
+                prev = cur
+            out = prev.result()
+        else:
+            for _ in range(count):
+                out = index.search(q, k)
+        return out
+
+    run(2)
+    torch.cuda.synchronize()
+    dist.barrier()
+    index.local.scan_timing(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s, i = run(steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    index.check()
+    st = index.margin_stats()  # (collective: summed over the shards)
+    ms, cnt = index.local.scan_timing()
+    scan_ms = ms / max(1, cnt)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    per = torch.zeros(world, 2, dtype=torch.float64, device=coll_dev)
+    per[rank, 0], per[rank, 1] = float(local_rows), scan_ms
+    dist.all_reduce(per)
+    chk = torch.stack([i.sum().to(torch.float64), s.double().sum()]).to(t.device)
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    esz = 1 if dtype != "bf16" else 2
+    peak = PEAK_FP8_TFLOPS if esz == 1 else PEAK_BF16_TFLOPS
+    per = per.cpu().tolist()
+    gpus = [{"rank": r, "rows": int(per[r][0]), "scan_kernel_ms": per[r][1],
+             "mfma_frac": (2.0 * nq * per[r][0] * d / (per[r][1] * 1e-3) / (peak * 1e12)) if per[r][1] > 0 else None,
+             "hbm_frac": ((per[r][0] * d * esz + nq * d * esz + nq * k * 12.0) / (per[r][1] * 1e-3) / (PEAK_HBM_GBS * 1e9)) if per[r][1] > 0 else None}
+            for r in range(world)]
+    kernel = index.local.last_kernel
+    del index
+    torch.cuda.empty_cache()
+    return {"workload": f"{rows}x{d} {dtype} index row-sharded x{world} (BASELINE config {'5' if esz == 1 else '3'}"
+                        f"{'' if rows == 1 << 24 else ' at reduced size'}), Q={nq} replicated, k={k}, 1 all-gather + merge per step",
+            "queries_per_s": nq * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "steps": steps, "scaling": "strong",
+            "pipelined_exchange": bool(pipelined), "kernel": kernel, "per_gpu": gpus, "ranks_agree": bool(torch.equal(lo, hi)),
+            "margin": st, "distributed": dist_info}
 
 
 def regime_certified(ram, torch, rows, d, nq, device, iters=5):
@@ -368,8 +437,12 @@ def main():
             raise SystemExit("ranks disagree on the merged top-k")
     scan_ms_sum, scan_launches = index.local.scan_timing()
     scan_ms = scan_ms_sum / max(1, scan_launches)
-    # margin check of the last timed search on this rank's shard (counted on the device, read now: the run is over)
-    margin = index.local.margin_stats(synchronize=True)
+    # margin check of the last timed search, summed over the shards (read now: the run is over).  A query left `unresolved`
+    # kept an uncertified first result: the headline number is then not the number of an exact search, and is not printed.
+    margin = index.margin_stats(synchronize=True)
+    if margin["unresolved"] > 0:
+        raise SystemExit(f"the timed searches left {margin['unresolved']} of {nq} queries unresolved (flagged {margin['flagged']}): "
+                         "not an exact search -- no value is reported")
 
     ms_per_step = elapsed / args.steps * 1e3
     value = nq * args.steps / elapsed
@@ -452,7 +525,22 @@ def main():
         free_b, _ = torch.cuda.mem_get_info()
         if free_b > 40e9:
             regimes = regime(ram, torch, 1 << 24, 768, [4096, 8], k, "bf16", local_rank, [5, 20])
+            regimes += regime(ram, torch, 1 << 22, 1024, [4096, 8], k, "bf16", local_rank, [5, 20])   # row pitch 1024 (BASELINE config 4's rows)
             regimes += regime_certified(ram, torch, n, d, nq, local_rank)
+    if world > 1 and not args.no_regimes:
+        # the configuration the north star quotes scaling on (BASELINE config 3: 2^24 x 768 bf16, row-sharded) and config 5 (e4m3
+        # rows) -- measured in this same N-rank run, after the headline, so that the driver's 1/2/4/8 curve carries them
+        del index
+        torch.cuda.empty_cache()
+        rrows = args.regime_rows if args.regime_rows > 0 else ((1 << 24) if n == (1 << 20) else 4 * n)
+        regimes = []
+        for rdt in ("bf16", "fp8_e4m3"):
+            need = -(-rrows // world) * d * (2 if rdt == "bf16" else 1) * 1.3
+            ok = torch.tensor([1 if torch.cuda.mem_get_info()[0] > need else 0], device=coll_dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()):
+                regimes.append(regime_sharded(ram, torch, dist, rrows, d, nq, k, rdt, local_rank, world, rank, max(3, min(args.steps, 10)),
+                                              pipelined, coll_dev, dist_info))
 
     if rank == 0:
         out = {
@@ -468,11 +556,11 @@ def main():
                        "rows_per_gpu": rows_per_gpu if world > 1 else local_rows},
             "distributed": dist_info,
             "step_ms": step_stats,
-            "margin_check": {"flagged_queries_last_step": margin["flagged"], "of": nq,
-                             "mode": ("count only: searches below nq x rows x d = 1.5e12 per GPU do not run the certificate")
-                                     if float(nq) * local_rows * d < 1.5e12 else
-                                     ("certified on the stream: searches of this size settle the queries they flag exactly (brute force on the "
-                                      "canonical scores, one pass over the index per 8 flagged queries), without synchronising"),
+            "margin_check": {"flagged_queries_last_step": margin["flagged"], "settled_exactly": margin["rescanned"],
+                             "unresolved": margin["unresolved"], "of": nq,
+                             "mode": "certified on the stream: every search settles the queries it flags exactly (brute force on the canonical "
+                                     "scores, one pass over the index per 8 flagged queries), without synchronising; a run that leaves a "
+                                     "query unresolved prints no value",
                              "bound": "exact k-th score within d*2^-23*|q|*max|x| of the best MFMA score outside the candidate pool"},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_torch": cpu_t, "parity_vs_cpu_sample": parity,
             "regimes": regimes,

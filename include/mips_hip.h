@@ -92,13 +92,16 @@ const char* mips_last_error(void);
  * doc_dtype is the storage type in HBM:
  *   MIPS_DTYPE_BF16      2 B/element, inputs rounded to bf16 (RNE); the fast path
  *   MIPS_DTYPE_FP8_E4M3  1 B/element, inputs AND queries rounded to OCP e4m3 (d <= 1024, k <= 13)
- *   MIPS_DTYPE_F32       fp32-exact: results are those of an fp32 brute force on the caller's values
+ *   MIPS_DTYPE_F32       fp32-exact: results are those of an fp32 brute force on the caller's values -- what the Python
+ *                        facade (Mips / KnowledgeBase.add_faiss_index / inner_product) creates by default, because the
+ *                        reference's embeddings are fp32 and "drop-in" means ITS neighbours
  *                        (bf16 hi|lo planes for the three-segment scan + the fp32 rows for the exact re-score, 8 B/element;
- *                        for d <= 1024 also bf16(x) alone at the fast kernels' row pitch, + 2 B/element: for d <= 768 searches that
- *                        certify (host buffers; device outputs re-scan on the stream, see mips_index_margin_stats) scan
- *                        THAT like a bf16 index, re-score on the fp32 rows, and send only the queries whose margin -- widened by the
- *                        representation error |x - bf16 x| |q| + |bf16 x| |q - bf16 q| -- is not certified through the
- *                        three-segment scan: same results, ~3x the rate on well-separated data; "f32_fast" below). */
+ *                        for d <= 1024 also bf16(x) alone at the fast kernels' row pitch, + 2 B/element: searches that
+ *                        certify (host buffers; device outputs certify on the stream, see mips_index_margin_stats) scan
+ *                        THAT like a bf16 index, re-score on the fp32 rows, and settle the queries whose margin -- widened by the
+ *                        representation error |x - bf16 x| |q| + |bf16 x| |q - bf16 q| -- is not certified by the exact pass
+ *                        over the fp32 rows: same results, ~5x the rate on well-separated data; "f32_fast" below.  The
+ *                        one-launch kernel of mips_search_fused serves this storage as well). */
 int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, int metric);
 
 /* Free the index and its scratch.  Replaces Dataset.drop_index (mips.py:537). */
@@ -164,8 +167,9 @@ int mips_search(mips_index_t* index, const void* q, int q_dtype, int64_t nq, int
  * two alternating scratch sets, so the scan of search t + 1 starts right behind the scan of search t while the tail
  * of t -- and whatever the caller enqueues behind it on tail_stream: the all-gather and merge of a row-sharded search
  * (sharded.py) -- runs beside it.  The results are complete on tail_stream; any other stream must wait for it (an
- * event recorded on tail_stream after the call).  Margin check: counted only (mips_index_margin_stats).  Nothing in
- * the reference corresponds. */
+ * event recorded on tail_stream after the call).  Margin check: as mips_search with device outputs -- the exact pass over the
+ * flagged queries is part of the tail (mips_index_margin_stats waits for it when asked to synchronise).  Nothing in the
+ * reference corresponds. */
 int mips_search_split(mips_index_t* index, const void* q, int q_dtype, int64_t nq, int k, float* out_scores,
                       int64_t* out_idx, int64_t idx_offset, int flags, void* scan_stream, void* tail_stream);
 
@@ -175,11 +179,13 @@ int mips_search_split(mips_index_t* index, const void* q, int q_dtype, int64_t n
  * buffers, stream-ordered, no host hop:
  *   q_device [nq, d] float32 or bf16; normalize != 0 (float32 only): faiss.normalize_L2 arithmetic, the caller's
  *   buffer is NOT modified; ignore_device [nq] int64 or NULL; out_scores / out_idx DEVICE [nq, k].
- * For the reference's own call shape (nq <= 16, bf16 index of <= 65536 rows, k + 1 <= 6) all of it is ONE kernel launch
- * (csrc/tiny_search.hpp: staging, MFMA scan, select, exact re-score, filter); other shapes run the same steps as
- * separate launches.  Results are identical either way ("tiny" = 0 in mips_index_set_param forces the general path,
- * "tiny" = 2 the one-launch kernel with its fall-back selection and sequential re-score -- test knobs; mips_search
- * takes the one-launch kernel for eligible shapes as well). */
+ * For the reference's own call shape (nq <= 16, bf16 or fp32-exact index of <= 65536 rows, k + 1 <= 6) all of it is ONE
+ * kernel launch (csrc/tiny_search.hpp: staging, MFMA scan, select, exact re-score, filter) followed -- unless the margin check
+ * is off or "count only" -- by the stream-ordered exact pass over the queries that kernel flagged (two launches that leave at
+ * once when nothing was flagged; the ignore filter is applied to their result too): the hook's results are CERTIFIED without a
+ * synchronisation.  Other shapes run the same steps as separate launches.  Results are identical either way ("tiny" = 0 in
+ * mips_index_set_param forces the general path, "tiny" = 2 the one-launch kernel with its fall-back selection and sequential
+ * re-score -- test knobs; mips_search takes the one-launch kernel for eligible shapes as well). */
 int mips_search_fused(mips_index_t* index, const void* q_device, int q_dtype, int64_t nq, int k, int normalize,
                       const int64_t* ignore_device, float* out_scores_device, int64_t* out_idx_device,
                       int64_t idx_offset, void* hip_stream);
@@ -242,14 +248,15 @@ int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out
  * to a multiple of 8), "qgroups" = query-tile groups per XCD octet (1, 2, 4 or 8), "variant" = scan kernel (1 = 128x128
  * register-staged tiles, 3 = query-stationary on the 32x32x16 MFMA shape, 4 = query-stationary on the
  * 16x16x32 shape (d padding to 384 .. 768, k <= 5)).  Results never depend on these four; only speed does.
- * "margin_check" (0 / 1 / 2) selects what happens to queries whose candidate pool is not provably wide enough: see
- * mips_index_margin_stats.  "f32_fast" (fp32-exact index): 0 = always the three-segment scan, 1 (default) = two-stage search
- * when the call may synchronise, skipped for 8 calls after one that sent more than a quarter of its queries to the second
- * stage, 2 = two-stage always (device-output searches then only COUNT the uncertified queries, like every margin check).
- * The same switch (alias "optimistic") governs bf16 searches with 8 <= k <= 13 that certify (host buffers or "margin_check" = 2)
- * at row pitches 384 .. 768: their pool of 32 candidates is then selected from the 16x16x32 kernel's sub-lists (the fast
- * kernel) instead of from true K' = 16 lists; the margin check decides per query whether that pool was wide enough and the
- * others are re-scanned with K' = 32 lists.
+ * "margin_check" (0 .. 4) selects what happens to queries whose candidate pool is not provably wide enough: see
+ * mips_index_margin_stats.  "resolve_budget" (default 0 = 1024): flagged queries one search settles at most.
+ * "f32_fast" (fp32-exact index): 0 = always the three-segment scan, 1 (default) = two-stage search in every call that certifies
+ * (which is every call unless "margin_check" is 0 or 4), skipped for 8 calls after a SYNCHRONISING call (host buffers,
+ * "margin_check" = 2) that sent more than an eighth of its queries to the second stage -- stream-ordered calls never change
+ * the path of later ones -- 2 = two-stage always (with "margin_check" = 4 the uncertified queries are then only COUNTED).
+ * The same switch (alias "optimistic") governs bf16 searches with 8 <= k <= 13 that certify at row pitches 384 .. 768: their
+ * pool of 32 candidates is then selected from the 16x16x32 kernel's sub-lists (the fast kernel) instead of from true K' = 16
+ * lists; the margin check decides per query whether that pool was wide enough and the others are settled exactly.
  * Two more names exist for tests and experiments and are NOT tuning knobs:
  *   "spin_limit"  polls a wave spends on the scan's block barrier before it gives up (0 = the shipped 2^22).  A tiny
  *                 value makes the kernel give up spuriously and -1 makes every scan launch raise its error word
@@ -276,30 +283,32 @@ int mips_index_check_error(mips_index_t* index, int synchronize, void* hip_strea
  * best MFMA score B anything OUTSIDE the pool can have had (unpopped list entries, documents rejected by an insert
  * bound, documents dropped from a full running list) and FLAGS the query when B + e >= tk, e = d 2^-23 |q| max|x|
  * (a rigorous bound for fp32 accumulation of the exact bf16 / e4m3 products).  "margin_check" (mips_index_set_param):
- *   0  off;
- *   1  (default) flag and count on the device -- nothing synchronises; read the count with this call.  Two exceptions,
- *      both still without synchronising, where device-output searches behave as in mode 3:
- *      - where a certificate buys a faster scan (fp32-exact index with d <= 768; 8 <= k <= 13 on a bf16 index at row
- *        pitch 384 .. 768); "f32_fast" = 0 keeps those on the plain scans;
- *      - searches whose scan takes milliseconds (nq x rows x d >= 1.5e12: from half of a 4096 x 2^20 x 768 search up),
- *        where the certificate's launches cost less than 1 % -- with a budget: a search that flags more than nq / 512
- *        queries (at least 8, at most 16: one or two passes; near-duplicate-heavy data) keeps its first results and
- *        counts them unresolved -- "margin_check" = 3 lifts the budget to 1024;
- *   2  certify: flagged queries are settled EXACTLY -- one pass over the stored rows per 8 flagged queries computes the
- *      canonical scores by brute force (csrc/resolve_kernels.hpp) and the rows reaching the current k-th result are ranked
- *      over it -- and mips_search synchronises to read the counts.  Searches into HOST buffers synchronise anyway and always
- *      do this unless the check is off.  (Rows of more than 1024 columns, searches that flag more than 1024 queries, and
- *      "resolve" = 0: re-scan of the flagged queries with the widest lists, K' = 32 / 16 on fp8, as in the first version.)
- *   3  the same WITHOUT synchronising (device outputs): flag list and count live on the device, the passes are enqueued
- *      behind the first scan and leave at once when nothing is flagged (tens of microseconds).  Searches in this mode
- *      also take the optimistic / two-stage paths ("f32_fast") and never the one-launch kernel; split-tail searches
- *      (mips_search_split) run the passes on their tail stream; more than 1024 flagged queries stay unresolved
- *      (counted).  Host-buffer searches behave as in mode 2.
+ *   0  off (an fp32-exact index then always runs the three-segment scan);
+ *   1  (default) CERTIFY: flagged queries are settled EXACTLY -- one pass over the stored rows per 8 flagged queries computes
+ *      the canonical scores by brute force (csrc/resolve_kernels.hpp) and the rows reaching the current k-th result are
+ *      ranked over it.  Searches into HOST buffers synchronise anyway: they read the flag count first and skip the pass
+ *      when it is 0.  Searches with DEVICE outputs never synchronise: flag list and count live on the device, the passes
+ *      are enqueued behind the first scan and leave at once when nothing is flagged (a few microseconds), graph-capturable;
+ *      split-tail searches (mips_search_split) run them on their tail stream.  The one-launch kernel (mips_search_fused,
+ *      small searches) hands its flags to the same pass.  A search that flags more than "resolve_budget" queries
+ *      (default 1024 = 128 passes): host buffers -> re-scan of the flagged queries with the widest lists (K' = 32; 16 on
+ *      fp8) as in the first version; device outputs -> the first results stand, counted `unresolved` -- unless the first
+ *      scan was an OPTIMISTIC one (two-stage fp32 search, pools of 32 out of sub-lists: candidates selected by bf16 scores
+ *      or short lists), whose results may not stand uncertified: a stream-ordered re-scan with true K' = 32 lists (the
+ *      three-segment scan on an fp32-exact index), sized on the device, runs exactly then.
+ *      (Rows of more than 1024 columns and "resolve" = 0: the re-scan with the widest lists instead of the exact pass.)
+ *   2  the same, and device-output searches synchronise as well to read the counts (mips_index_margin_stats is then free);
+ *   3  the stream-ordered form of 1, explicitly (kept for callers of the round-2 library: identical to 1 for device
+ *      outputs);
+ *   4  count only: device-output searches flag and count on the device and do nothing about it (the round-2 default;
+ *      an fp32-exact index then cannot use the scans that rest on the certificate); host-buffer searches still certify.
  * Outputs of the LAST search on the index: flagged = queries flagged by the first pass (-1: only counted on the
- * device and synchronize == 0), rescanned = queries settled exactly (or re-scanned), unresolved = queries left with their
- * first result: more than 64 rows tie with the k-th result exactly, or the search flagged more than it resolves (on tie-free
- * data the first result is exact in practice -- the MFMA error observed is ~sqrt(d) 2^-24, two orders of magnitude below
- * the bound).  Nothing in the reference corresponds (faiss IndexFlat computes its scores in fp32 as well and offers no
+ * device and synchronize == 0), rescanned = queries settled exactly (or re-scanned; 0 for a search over its budget whose first
+ * results stand), unresolved = queries left with their first result: more than 64 rows tie with the k-th result exactly, or the
+ * search flagged more than it resolves.  What an unresolved first result is worth depends on the first scan: true K'-entry
+ * lists of bf16 / e4m3 products accumulated in fp32 are exact in practice on tie-free data (the MFMA error observed is
+ * ~sqrt(d) 2^-24, two orders of magnitude below the bound); the optimistic scans never leave one behind (mode 1 above).
+ * With synchronize != 0 the call also waits for the tail stream of a split-tail search.  Nothing in the reference corresponds (faiss IndexFlat computes its scores in fp32 as well and offers no
  * certificate). */
 int mips_index_margin_stats(mips_index_t* index, int64_t* flagged, int64_t* rescanned, int64_t* unresolved,
                             int synchronize, void* hip_stream);

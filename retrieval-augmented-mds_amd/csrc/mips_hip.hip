@@ -163,6 +163,8 @@ struct mips_index {
     bool xmax2_valid = false;
     unsigned* nflag_host = nullptr; // pinned: flagged-query count of the last certified search
     int64_t last_flagged = -1, last_rescanned = 0, last_unresolved = 0;
+    bool last_fallback = false; // the last search enqueued the gated fall-back re-scan behind its exact pass
+    int last_max_n = 0; // flagged queries the exact pass of the last search would resolve at most (statistics: over budget = none settled)
     int rescan_depth = 0;
     unsigned* last_nflag_dev = nullptr;
     // Split-tail searches (mips_search_split): the scan runs on one stream, select + exact re-score on another, so the
@@ -1044,6 +1046,7 @@ int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
     int* cnt = ids + nq;
     unsigned* unres = (unsigned*)(ids + nq + 1);
     if (!ix->nflag_host) HIP_TRY(hipHostMalloc((void**)&ix->nflag_host, 64, hipHostMallocDefault));
+    const int max_n = ix->resolve_budget > 0 ? std::min(ix->resolve_budget, mips::RESOLVE_MAX) : mips::RESOLVE_MAX;
     if (!skip_compact)
         mips::compact_flags_kernel<<<1, 256, 0, st>>>((const unsigned char*)ix->mflag.p, (int)nq, ids, cnt, (int*)ix->hit_n.p, mips::RESOLVE_MAX, unres);
     if (certify_now) {
@@ -1054,7 +1057,7 @@ int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
         ix->last_rescanned = 0;
         ix->last_unresolved = 0;
         if (n == 0) return MIPS_OK;
-        if (n > mips::RESOLVE_MAX) return kUseRescan;
+        if (n > max_n && !skip_compact) return kUseRescan; // (the one-launch kernel's <= 16 queries have no tile re-scan to go to)
     }
     mips::ResolveArgs a;
     const bool f32x = ix->plane > 0;
@@ -1064,7 +1067,9 @@ int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
     a.ntotal = ix->ntotal;
     a.ids = ids;
     a.n_dev = cnt;
-    a.max_n = ix->resolve_budget > 0 ? std::min(ix->resolve_budget, mips::RESOLVE_MAX) : mips::RESOLVE_MAX;
+    a.max_n = max_n;
+    ix->last_max_n = a.max_n;
+    ix->last_fallback = false;
     a.keyk = (const float*)ix->keyk.p;
     a.qq = (const double*)ix->qqv.p;
     a.phi = ix->phi;
@@ -1101,7 +1106,7 @@ int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
     if (certify_now) {
         HIP_TRY(hipMemcpyAsync(&ix->nflag_host[1], unres, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        ix->last_rescanned = ix->last_flagged;
+        ix->last_rescanned = ix->last_flagged > a.max_n ? 0 : ix->last_flagged; // (over the budget: nothing was settled)
         ix->last_unresolved = (int64_t)ix->nflag_host[1];
     } else {
         ix->last_flagged = -1; // (device only: mips_index_margin_stats fetches the two counters when asked)
@@ -1123,7 +1128,10 @@ int rescan_on_stream(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i
                      int gate_above = -1) {
     const bool f8 = ix->esize == 1;
     const int wide = f8 ? (KL < 16 ? 16 : 0) : (KL < 32 || fast_first ? 32 : 0);
-    if (gate_above < 0) ix->last_flagged = -1; // (device only)
+    if (gate_above < 0) {
+        ix->last_flagged = -1; // (device only)
+        ix->last_max_n = 0;
+    }
     if (wide == 0) return MIPS_OK; // already on the widest lists: counted only
     const int64_t n_pad = round_up(nq, kQueryAlign);
     const size_t row_bytes = (size_t)ix->ld * ix->esize;
@@ -1185,6 +1193,7 @@ int rescan_on_stream(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i
         HIP_TRY(hipGetLastError());
         ix->first_nflag_dev = first_keep;
         ix->last_nflag_dev = exact_unres;
+        ix->last_fallback = true;
         return MIPS_OK;
     }
     ix->first_nflag_dev = (const int*)cnt; // last_nflag_dev: the re-scan's own counter (still flagged on the widest lists)
@@ -1702,21 +1711,15 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
             HIP_TRY(hipMemcpyAsync(ix->stage.p, q, qbytes, hipMemcpyHostToDevice, st));
             qd = ix->stage.p;
         }
-        const bool stream_ordered = out_dev && ix->opt_margin == 3;
-        int rc = tiny_search(ix, qd, q_dtype, nq, k, k, 0, nullptr, d_s, d_i, packed, idx_offset, st, stream_ordered);
+        int rc = tiny_search(ix, qd, q_dtype, nq, k, k, 0, nullptr, d_s, d_i, packed, idx_offset, st, certifies);
         if (rc) return rc;
         done = true;
-        if (stream_ordered) { // the exact pass behind the one launch: leaves at once when nothing was flagged (the kernel, and
-            // with it its results, live on the scan stream even in the split-tail form)
-            rc = resolve_flagged(ix, nq, k, d_s, d_i, packed, idx_offset, st, false, /*skip_compact=*/true);
-            if (rc) return rc;
-        } else if (ix->opt_margin != 0 && (!out_dev || ix->opt_margin == 2)) {
-            // certify: a flagged query sends the whole (tiny) call through the general path and its re-scan
-            if (!ix->nflag_host) HIP_TRY(hipHostMalloc((void**)&ix->nflag_host, 64, hipHostMallocDefault));
-            HIP_TRY(hipMemcpyAsync(ix->nflag_host, ix->last_nflag_dev, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            ix->last_flagged = (int64_t)ix->nflag_host[0];
-            done = ix->last_flagged == 0;
+        if (certifies) {
+            // the exact pass behind the one launch (the kernel, and with it its results, live on the scan stream even in the
+            // split-tail form).  Device outputs: enqueued blind, it leaves at once when nothing was flagged; host buffers and
+            // "margin_check" = 2 synchronise, read the count and skip it when that is 0
+            rc = resolve_flagged(ix, nq, k, d_s, d_i, packed, idx_offset, st, /*certify_now=*/!(out_dev && ix->opt_margin == 3), /*skip_compact=*/true);
+            if (rc < 0) return rc; // (kUseRescan cannot happen: <= 16 queries)
         }
     }
     if (!done) {
@@ -1846,21 +1849,16 @@ int mips_search_fused(mips_index_t* ix, const void* q_device, int q_dtype, int64
                 int rc = compute_phi(ix, st);
                 if (rc) return rc;
             }
-            const bool stream_ordered = ix->opt_margin == 3;
             int rc = tiny_search(ix, q_device, q_dtype, nq, k_fetch, k, normalize, ignore_device, out_scores_device, out_idx_device, false,
-                                 idx_offset, st, stream_ordered);
+                                 idx_offset, st, certifies);
             if (rc) return rc;
-            if (stream_ordered) // certified without a synchronisation: the exact pass behind the one launch (it leaves at once when
-                                // nothing was flagged) ranks the hits of a flagged query and applies the same ignore filter
-                return resolve_flagged(ix, nq, k_fetch, out_scores_device, out_idx_device, false, idx_offset, st, false, /*skip_compact=*/true,
-                                       ignore_device, k);
-            if (ix->opt_margin != 2) return MIPS_OK;
-            if (!ix->nflag_host) HIP_TRY(hipHostMalloc((void**)&ix->nflag_host, 64, hipHostMallocDefault));
-            HIP_TRY(hipMemcpyAsync(ix->nflag_host, ix->last_nflag_dev, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            ix->last_flagged = (int64_t)ix->nflag_host[0];
-            if (ix->last_flagged == 0) return MIPS_OK;
-            // a flagged query: the unfused path below certifies it
+            if (!certifies) return MIPS_OK; // ("margin_check" = 4 / 0: flagged queries are counted, or not even that)
+            // certified: the exact pass behind the one launch ranks the hits of a flagged query and applies the same ignore
+            // filter -- without a synchronisation by default (it leaves at once when nothing was flagged); "margin_check" = 2
+            // synchronises to read the counts
+            rc = resolve_flagged(ix, nq, k_fetch, out_scores_device, out_idx_device, false, idx_offset, st, /*certify_now=*/ix->opt_margin == 2,
+                                 /*skip_compact=*/true, ignore_device, k);
+            return rc < 0 ? rc : MIPS_OK;
         }
     }
     // general form: the same steps as separate launches
@@ -2072,8 +2070,9 @@ int mips_index_margin_stats(mips_index_t* ix, int64_t* flagged, int64_t* rescann
         HIP_TRY(hipMemcpyAsync(&n[1], ix->last_nflag_dev, 4, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
         HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
         ix->last_flagged = (int64_t)n[0];
-        ix->last_rescanned = (int64_t)n[0];
         ix->last_unresolved = (int64_t)n[1];
+        // settled exactly (or re-scanned by the fall-back); a search over its budget whose first results stand settled nothing
+        ix->last_rescanned = (ix->last_max_n > 0 && (int64_t)n[0] > ix->last_max_n && !ix->last_fallback) ? 0 : (int64_t)n[0];
     } else if (ix->last_flagged < 0 && synchronize && ix->opt_margin != 0 && ix->last_nflag_dev != nullptr) {
         // the last search only counted on the device: fetch the count now
         DeviceGuard g(ix->device);

@@ -342,16 +342,17 @@ __device__ __forceinline__ float tiny_lb(const float* pb, int npre, int lane) {
 // moves, ~4 us, two waves per SIMD filling each other's latency.  x: global or LDS (generic), y: LDS.  Result on sub == 0.
 __device__ __forceinline__ double tiny_seq_dot_f32(const float* x, const float* y, int nchunk, int sub) {
     double acc = 0.0;
-    u32x4 xr[8];
+    // the whole row (<= 1024 columns = 4 groups of 64 chunks) is requested before the first use: one memory round trip
+    u32x4 xr[8], x1[8], x2[8], x3[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
+    for (int t = 0; t < 8; ++t) {
         if (8 * t < nchunk) xr[t] = *reinterpret_cast<const u32x4*>(x + (sub + 8 * t) * 4);
+        if (64 + 8 * t < nchunk) x1[t] = *reinterpret_cast<const u32x4*>(x + (64 + sub + 8 * t) * 4);
+        if (128 + 8 * t < nchunk) x2[t] = *reinterpret_cast<const u32x4*>(x + (128 + sub + 8 * t) * 4);
+        if (192 + 8 * t < nchunk) x3[t] = *reinterpret_cast<const u32x4*>(x + (192 + sub + 8 * t) * 4);
+    }
 #pragma unroll 1
     for (int h0 = 0; h0 < nchunk; h0 += 64) { // groups of 64 chunks = 256 columns: a LOOP (code size, see the staging comment)
-        u32x4 xn[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-            if (h0 + 64 + 8 * t < nchunk) xn[t] = *reinterpret_cast<const u32x4*>(x + (h0 + 64 + sub + 8 * t) * 4);
 #pragma unroll
         for (int t = 0; t < 8; ++t)
             if (h0 + 8 * t < nchunk) { // (uniform)
@@ -371,7 +372,11 @@ __device__ __forceinline__ double tiny_seq_dot_f32(const float* x, const float* 
                 }
             }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) xr[t] = xn[t];
+        for (int t = 0; t < 8; ++t) {
+            xr[t] = x1[t];
+            x1[t] = x2[t];
+            x2[t] = x3[t];
+        }
     }
     return acc;
 }
@@ -581,11 +586,26 @@ __global__ __launch_bounds__(TINY_THREADS, 1) void tiny_search_kernel(TinyArgs a
             const float* x = a.rows_f32 + (size_t)(id != IDX_NONE ? id : 0) * a.plane;
             const float* y = qf + (size_t)q * a.plane;
             double acc = 0.0;
-            for (int ch = sub; ch < a.plane / 4; ch += 8) {
-                const u32x4 xv = *reinterpret_cast<const u32x4*>(x + ch * 4);
-                const u32x4 yv = *reinterpret_cast<const u32x4*>(y + ch * 4);
+            {   // chunks sub, sub + 8, ...: two groups of 16 per lane (<= 1024 columns), BOTH requested before the first use
+                const int nch = a.plane / 4; // a multiple of 16
+                u32x4 xa[16], xb[16];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc += (double)__uint_as_float(xv[e]) * (double)__uint_as_float(yv[e]);
+                for (int t = 0; t < 16; ++t) {
+                    if (8 * t < nch) xa[t] = *reinterpret_cast<const u32x4*>(x + (sub + 8 * t) * 4);
+                    if (128 + 8 * t < nch) xb[t] = *reinterpret_cast<const u32x4*>(x + (128 + sub + 8 * t) * 4);
+                }
+#pragma unroll 1
+                for (int h0 = 0; h0 < nch; h0 += 128) {
+#pragma unroll
+                    for (int t = 0; t < 16; ++t)
+                        if (h0 + 8 * t < nch) {
+                            const u32x4 yv = *reinterpret_cast<const u32x4*>(y + (h0 + sub + 8 * t) * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc += (double)__uint_as_float(xa[t][e]) * (double)__uint_as_float(yv[e]);
+                        }
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) xa[t] = xb[t];
+                }
             }
             acc += tiny_dpp<DPP_XOR1>(acc);
             acc += tiny_dpp<DPP_XOR2>(acc);

@@ -191,9 +191,24 @@ class ShardedMipsIndex:
         also opens the optimistic / two-stage paths (8 <= k <= 13, fp32-exact shards) to the sharded search."""
         self.local.set_param(name, value)
 
-    def margin_stats(self, synchronize: bool = True) -> dict:
-        """Margin statistics of the last LOCAL search (MipsIndex.margin_stats)."""
-        return self.local.margin_stats(synchronize)
+    def margin_stats(self, synchronize: bool = True, reduce: bool = True) -> dict:
+        """Margin statistics of the last search: the shards' counts (MipsIndex.margin_stats) SUMMED over the ranks -- a query
+        left unresolved on any shard is unresolved in the merged result, so `unresolved` must be visible everywhere.  The sum
+        is one small all-reduce: COLLECTIVE, every rank calls it (synchronize=True only; reduce=False or synchronize=False
+        return this rank's own counts without communicating)."""
+        st = self.local.margin_stats(synchronize)
+        if not (reduce and synchronize and self.world > 1):
+            return st
+        import torch
+        import torch.distributed as dist
+
+        backend = dist.get_backend(self.group)
+        t = torch.tensor([st["flagged"], st["rescanned"], st["unresolved"]], dtype=torch.int64,
+                         device=f"cuda:{self.local.device}" if backend == "nccl" else "cpu")
+        t = torch.clamp(t, min=0)  # (-1 = "only counted on the device" cannot survive a synchronising read)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        f, r, u = (int(v) for v in t.cpu().tolist())
+        return {"flagged": f, "rescanned": r, "unresolved": u}
 
     def check(self, synchronize: bool = True) -> None:
         """MipsIndex.check for this rank's shard.  A shard whose scan timed out hands poisoned rows (idx -2, NaN)

@@ -364,3 +364,37 @@ def test_embedding_shard_files_roundtrip(tmp_path):
     empty = ram.Mips(ram.MipsArgs(mips_tmp_folder=str(tmp_path / "none")))
     with pytest.raises(ValueError, match="no embedding shards"):
         empty._load_embedding_shards()
+
+
+def test_faiss_shim_surface_without_a_gpu(tmp_path, monkeypatch):
+    """faiss_shim: the module-level surface HF `datasets` and sotasum/mips.py touch -- constants, normalize_L2, the factory's
+    refusal of anything but "Flat", argument checks, install() -- none of which needs the GPU (index storage is created lazily)."""
+    import sys as _s
+
+    fs = ram.faiss_shim
+    assert (fs.METRIC_INNER_PRODUCT, fs.METRIC_L2) == (0, 1)
+    x = np.arange(12, dtype=np.float32).reshape(3, 4)
+    x[0] = 0
+    ref = orc.l2_normalization(x.copy())
+    fs.normalize_L2(x)
+    assert np.array_equal(x, ref) and (x[0] == 0).all()
+    with pytest.raises(TypeError):
+        fs.normalize_L2(np.zeros((2, 3), np.float64))
+    with pytest.raises(NotImplementedError, match="Flat"):
+        fs.index_factory(8, "IVF16,Flat", fs.METRIC_INNER_PRODUCT)
+    ix = fs.index_factory(8, "Flat", fs.METRIC_INNER_PRODUCT)
+    assert isinstance(ix, fs.IndexFlat) and ix.d == 8 and ix.ntotal == 0 and ix.is_trained and ix.metric_type == 0
+    ix.nprobe = 4
+    ix.verbose = True
+    assert ix.train(None) is None
+    with pytest.raises(ValueError):
+        ix.add(np.zeros((2, 7), np.float32))
+    l2 = fs.IndexFlat(5)                                       # faiss's default metric is L2
+    assert l2.metric_type == fs.METRIC_L2
+    with pytest.raises(NotImplementedError, match="phi-augmented"):
+        l2.add(np.array([[1, 0, 0, 0, 0], [3, 0, 0, 0, 1]], np.float32))   # rows of different norms: plain L2 is not this path
+    monkeypatch.delitem(_s.modules, "faiss", raising=False)
+    assert fs.install() is fs and _s.modules["faiss"] is fs
+    import importlib.util
+    assert importlib.util.find_spec("faiss") is not None      # what HF's `_has_faiss` asks
+    _s.modules.pop("faiss", None)

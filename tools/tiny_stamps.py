@@ -5,11 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import retrieval_augmented_mds_amd as ram
 
-for rows in (10000, 65536):
-    ix = ram.MipsIndex(768)
+for rows, dtype in ((10000, "bf16"), (65536, "bf16"), (10000, "f32"), (65536, "f32")):
+    ix = ram.MipsIndex(768, dtype=dtype)
     ix.add_synthetic(rows, 0, ram.SEED_DOCS, ram.SYNTH_GAUSS)
     q = ram.synth_fill(8, 768, 0, ram.SEED_QUERIES, ram.SYNTH_GAUSS)
-    print("rows", rows, file=sys.stderr, flush=True)
+    print("rows", rows, dtype, file=sys.stderr, flush=True)
     for _ in range(6):
         ix.search(q, 5)
         torch.cuda.synchronize()
