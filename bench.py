@@ -170,6 +170,7 @@ def regime(ram, torch, rows, d, nq, k, dtype, device, iters):
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / it
         ix.check()
+        st = ix.margin_stats()
         ms, cnt = ix.scan_timing()
         scan = ms / max(1, cnt) * 1e-3
         fl = 2.0 * q_n * rows * d
@@ -178,7 +179,7 @@ def regime(ram, torch, rows, d, nq, k, dtype, device, iters):
         hbm_bound = (by / (PEAK_HBM_GBS * 1e9)) > (fl / (peak * 1e12))
         out.append({
             "workload": f"{rows}x{d} {dtype} index, Q={q_n}, k={k}", "queries_per_s": q_n / wall, "call_ms": wall * 1e3,
-            "kernel": ix.last_kernel, "kernel_ms": scan * 1e3, "launches_timed": cnt,
+            "kernel": ix.last_kernel, "kernel_ms": scan * 1e3, "launches_timed": cnt, "flagged": st["flagged"], "unresolved": st["unresolved"],
             "bound": "hbm" if hbm_bound else "mfma",
             "mfma_achieved_tflops": fl / scan / 1e12, "mfma_frac": fl / scan / (peak * 1e12),
             "hbm_achieved_gbs": by / scan / 1e9, "hbm_frac": by / scan / (PEAK_HBM_GBS * 1e9),

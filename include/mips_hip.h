@@ -244,6 +244,11 @@ int mips_l2_normalize(float* x_device, int64_t n, int64_t d, int device, void* h
 int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out_host, int device,
                         void* hip_stream);
 
+/* The same maximum accumulated into a DEVICE double (acc_device = max(acc_device, max_i |x_i|^2); the caller zeroes it once):
+ * nothing is copied to the host, nothing synchronises.  For index builds that receive the rows in encoder batches
+ * (Mips.add_embeddings): the running max-norm stays on the device and is read once when the build ends. */
+int mips_rows_max_sumsq_device(const float* x_device, int64_t n, int64_t d, double* acc_device, int device, void* hip_stream);
+
 /* Tuning knobs of the scan launch (0 = automatic): "nsplit" = number of index splits (rounded up
  * to a multiple of 8), "qgroups" = query-tile groups per XCD octet (1, 2, 4 or 8), "variant" = scan kernel (1 = 128x128
  * register-staged tiles, 3 = query-stationary on the 32x32x16 MFMA shape, 4 = query-stationary on the

@@ -134,6 +134,7 @@ def _bind(lib):
         "mips_cosine_rescore_backward": (i32, [vp, vp, i32, i64, i32, i64, vp, vp, i64, vp, vp, i32, vp]),
         "mips_l2_normalize": (i32, [vp, i64, i64, i32, vp]),
         "mips_rows_max_sumsq": (i32, [vp, i64, i64, c.POINTER(c.c_double), i32, vp]),
+        "mips_rows_max_sumsq_device": (i32, [vp, i64, i64, vp, i32, vp]),
         "mips_index_set_param": (i32, [vp, c.c_char_p, i64]),
         "mips_scan_timing": (i32, [vp, c.POINTER(c.c_float), c.POINTER(c.c_int), i32]),
         "mips_index_check_error": (i32, [vp, i32, vp]),
@@ -154,6 +155,7 @@ EXPORTS = (
     "mips_index_add_synthetic", "mips_synth_fill", "mips_search", "mips_merge_topk",
     "mips_merge_topk_packed", "mips_filter_ignore", "mips_cosine_rescore", "mips_cosine_rescore_bias", "mips_l2_normalize", "mips_rows_max_sumsq", "mips_index_set_param", "mips_scan_timing",
     "mips_index_check_error", "mips_index_last_kernel", "mips_cosine_rescore_backward", "mips_index_margin_stats", "mips_search_fused", "mips_search_split",
+    "mips_rows_max_sumsq_device",
 )
 
 

@@ -445,7 +445,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     const bool v4_auto = variant == 0 && ix->opt_sub == 0 && v4_shape;
     if (variant != 1 && variant != 3) variant = 3; // (4 / 5 were decided above; the rest of the function only knows 1 and 3)
     const bool v3_dim = (ix->ld % 128 == 0 && ix->ld <= 768) || ix->ld == 1024;
-    const bool v3_long = ix->ld == 256 || ix->ld == 512 || ix->ld == 768; // pitches with K' = 16 / 32 instances
+    const bool v3_long = ix->ld == 256 || ix->ld == 512 || ix->ld == 768 || ix->ld == 1024; // pitches with K' = 16 / 32 instances
     constexpr bool kl_short = KL <= 10; // K' = 8 / 10 lists fit the 8-wave (two per SIMD) configuration
     const bool f8 = ix->esize == 1; // e4m3 index: scan_kernel_f8 only (row lengths 256..1024, K' <= 16)
     const bool f32x = ix->plane > 0; // fp32-exact mode: generic kernel over the [hi | lo] planes, three k segments
@@ -679,8 +679,8 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         mips::scan_kernel<KL><<<grid, mips::SCAN_THREADS, mips::SCAN_LDS_BYTES, st>>>(a);
         set_kernel_name(ix, "mips::scan_kernel<%d>", KL);
     } else if constexpr (!kl_short) {
-        // 4-wave configuration, 3-stage ring (d <= 768: 3 x 48 KiB)
-        const int lds = 3 * mips::V3_DB * ix->ld * 2 + 4 * 1024 + 1024 + 16;
+        // 4-wave configuration, 3-stage ring (d <= 768: 3 x 48 KiB; pitch 1024: 2 x 64 KiB)
+        const int lds = (ix->ld == 1024 ? 2 : 3) * mips::V3_DB * ix->ld * 2 + 4 * 1024 + 1024 + 16;
         auto go4 = [&](auto kern) -> int {
             HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             if (ix->timing_armed) HIP_TRY(hipEventRecord(ix->ev0[slot], st));
@@ -695,6 +695,12 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             set_kernel_name(ix, "mips::scan_kernel_v3 experimental instance sub=51 (4 waves, 2 stages)");
         } else
 #endif
+        if (ix->ld == 1024) { // (round 3: true K' = 16 / 32 lists at pitch 1024 -- k = 8 .. 29 and stage 1 of the two-stage fp32
+            // search at Longformer-large width no longer fall back to the generic kernel)
+            rc2 = nqt == 1 ? go4(mips::scan_kernel_v3<KL, 64, 1, 4, false, 0, 2, 4, 2, true, true>) : go4(mips::scan_kernel_v3<KL, 64, 1, 4, false, 0, 2, 4, 2>);
+            if (rc2) return rc2;
+            set_kernel_name(ix, nqt == 1 ? "mips::scan_kernel_v3<%d, 64, 1, 4, false, 0, 2, 4, 2, true, true, 8>" : "mips::scan_kernel_v3<%d, 64, 1, 4, false, 0, 2, 4, 2, true, false, 8>", KL);
+        } else
         if (nqt == 1) { // one query tile: non-temporal document DMA
             if (ix->ld == 768) rc2 = go4(mips::scan_kernel_v3<KL, 48, 1, 4, true, 0, 2, 4, 3, true, true>);
             else if (ix->ld == 512) rc2 = go4(mips::scan_kernel_v3<KL, 32, 1, 4, true, 0, 2, 4, 3, true, true>);
@@ -704,7 +710,8 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         else if (ix->ld == 512) rc2 = go4(mips::scan_kernel_v3<KL, 32, 1, 4, true, 0, 2, 4, 3>);
         else rc2 = go4(mips::scan_kernel_v3<KL, 16, 1, 4, true, 0, 2, 4, 3>);
         if (rc2) return rc2;
-        set_kernel_name(ix, nqt == 1 ? "mips::scan_kernel_v3<%d, %d, 1, 4, true, 0, 2, 4, 3, true, true, 8>" : "mips::scan_kernel_v3<%d, %d, 1, 4, true, 0, 2, 4, 3, true, false, 8>", KL, ix->ld / 16);
+        if (ix->ld != 1024)
+            set_kernel_name(ix, nqt == 1 ? "mips::scan_kernel_v3<%d, %d, 1, 4, true, 0, 2, 4, 3, true, true, 8>" : "mips::scan_kernel_v3<%d, %d, 1, 4, true, 0, 2, 4, 3, true, false, 8>", KL, ix->ld / 16);
     } else {
         const int lds = (v3_waves == 4 ? 2 : 3) * mips::V3_DB * ix->ld * 2 + v3_waves * 1024 + 1024 + 16; // ring + threshold words + dump area + arrival counter
         auto go = [&](auto kern, int threads) -> int {
@@ -1763,10 +1770,10 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
         // K' = 32 lists where the bf16 kernels have them (pitch 256 / 512 / 768): the pool's bound is then the ~33rd best
         // score, far enough below the k-th for the widened margin to certify nearly every query on well-separated data
         // (with K' = 8 pools 44 % of the queries of a Gaussian test set went to the second stage; pitch 1024 has no more).
-        const bool hi_long = ix->hp > 0 && ix->hp <= 768;
-        // (row pitch 1024 has pools of 8 only: 46 % of a Gaussian test set went to the second stage -- stage 1 does not pay
-        // there unless asked for with "f32_fast" = 2)
-        bool fast = ix->plane > 0 && ix->hp > 0 && (hi_long || (k <= 7 && ix->opt_f32_fast == 2)) && ix->opt_f32_fast != 0 && ix->opt_margin != 0 && !split &&
+        const bool hi_long = ix->hp > 0 && ix->hp <= 1024;
+        // (round 3: row pitch 1024 has true K' = 32 lists as well -- with pools of 8, all it had before, 46 % of a Gaussian
+        // test set went to the second stage and stage 1 did not pay)
+        bool fast = ix->plane > 0 && ix->hp > 0 && hi_long && ix->opt_f32_fast != 0 && ix->opt_margin != 0 && !split &&
                     (ix->opt_f32_fast == 2 || !out_dev || ix->opt_margin >= 2);
         if (fast && ix->opt_f32_fast == 1 && ix->fast_skip > 0) {
             --ix->fast_skip;
@@ -1794,8 +1801,10 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
             rc = scan_and_finish<8>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, tail_st, split, fast);
         } else if (k <= 7) { // k + 1 = 6 is what Mips.search fetches for top_k = 5 with ignore_indexes (mips.py:388-398)
             rc = scan_and_finish<10>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, tail_st, split, fast);
-        } else if (k <= 13) {
-            // bf16 index, a call that certifies: pool of 32 out of the 16x16x32 kernel's sub-lists (see mips_index::optimistic)
+        } else {
+            // bf16 index, a call that certifies, 8 <= k <= 29: pool of 32 out of the 16x16x32 kernel's sub-lists (see
+            // mips_index::optimistic; round 3: k = 14 .. 29 as well -- the class words vouch for 32 documents, what the
+            // sub-lists of 6 may have dropped is bounded, the margin check decides per query).  Otherwise true K' = 16 / 32 lists.
             bool opt = ix->plane == 0 && ix->esize == 2 && ix->opt_margin != 0 && !split && (!out_dev || ix->opt_margin >= 2) &&
                        ix->opt_f32_fast != 0 && ix->ld % 128 == 0 && ix->ld >= 384 && ix->ld <= 768;
             if (opt && ix->fast_skip > 0) {
@@ -1803,11 +1812,8 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
                 opt = false;
             }
             if (opt) rc = scan_and_finish<32>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, tail_st, split, false, true);
-            else rc = scan_and_finish<16>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, tail_st, split, false);
-        } else {
-            rc = launch_search<32>(ix, nq, k, d_s, d_i, packed ? d_i : nullptr, idx_offset, st, tail_st, split);
-            if (!rc && !split) rc = finish_margin<32>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st);
-            if (!rc && split) ix->last_flagged = -1; // counted on the device only
+            else if (k <= 13) rc = scan_and_finish<16>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, tail_st, split, false);
+            else rc = scan_and_finish<32>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, tail_st, split, false);
         }
         if (rc) return rc;
     }
@@ -2008,6 +2014,18 @@ int mips_rows_max_sumsq(const float* x_device, int64_t n, int64_t d, double* out
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return fail(MIPS_E_HIP, "mips_rows_max_sumsq: %s", hipGetErrorString(e));
     std::memcpy(out_host, &bits, 8);
+    return MIPS_OK;
+}
+
+int mips_rows_max_sumsq_device(const float* x_device, int64_t n, int64_t d, double* acc_device, int device, void* hip_stream) {
+    if (n < 0 || d <= 0 || (n > 0 && !x_device) || !acc_device) return fail(MIPS_E_INVALID, "mips_rows_max_sumsq_device: bad argument");
+    if (n == 0) return MIPS_OK;
+    DeviceGuard g(device);
+    if (!g.ok) return fail(MIPS_E_HIP, "hipSetDevice(%d) failed", device);
+    // (non-negative doubles order like their bit patterns: the kernel's atomicMax on the 64-bit word IS the running maximum)
+    mips::f32_rows_max_sumsq_kernel<<<(int)std::min<int64_t>((n + 3) / 4, 256 * 16), 256, 0, (hipStream_t)hip_stream>>>(
+        x_device, n, (int)d, (unsigned long long*)acc_device);
+    HIP_TRY(hipGetLastError());
     return MIPS_OK;
 }
 

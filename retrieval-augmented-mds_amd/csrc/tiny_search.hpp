@@ -621,7 +621,8 @@ __global__ __launch_bounds__(TINY_THREADS, 1) void tiny_search_kernel(TinyArgs a
             if (lane < TINY_POOL) { // re-sort by the refined score: the final level expects every list best first
                 int rank = 0;
 #pragma unroll
-                for (int t = 0; t < TINY_POOL; ++t) rank += ranks_before(sv[t], si[t], sv[lane], si[lane]) ? 1 : 0;
+                for (int t = 0; t < TINY_POOL; ++t) // (the empty slots -- all (-inf, IDX_NONE) -- are ordered by position: every rank is taken once)
+                    rank += (ranks_before(sv[t], si[t], sv[lane], si[lane]) || (si[t] == si[lane] && t < lane)) ? 1 : 0;
                 gps[o + rank] = sv[lane];
                 gpi[o + rank] = si[lane];
             }

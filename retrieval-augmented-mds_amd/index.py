@@ -388,6 +388,20 @@ def rows_max_sumsq(x) -> float:
     return out.value
 
 
+def rows_max_sumsq_into(x, acc) -> None:
+    """acc = max(acc, max_i |x_i|^2): `acc` is a CUDA float64 tensor of one element that stays on the device -- no host copy,
+    no synchronisation (the running max-norm of a streaming index build; read it once, at the end)."""
+    import torch
+
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2):
+        raise ValueError("rows_max_sumsq_into: expected a contiguous CUDA float32 matrix")
+    if not (isinstance(acc, torch.Tensor) and acc.is_cuda and acc.dtype == torch.float64 and acc.numel() == 1 and acc.device == x.device):
+        raise ValueError("rows_max_sumsq_into: the accumulator must be a one-element CUDA float64 tensor on the rows' device")
+    lib = _lib.load()
+    _lib.check(lib.mips_rows_max_sumsq_device(x.data_ptr(), x.shape[0], x.shape[1], acc.data_ptr(), x.device.index,
+                                              _stream_handle(x.device.index)), "mips_rows_max_sumsq_device")
+
+
 def merge_topk_packed(gathered, nq: int, parts: int, k: int, metric: int = _lib.METRIC_IP):
     """Device merge straight from the gathered payload: CUDA int64 [parts * nq, k, 2] (rank-major)."""
     import torch

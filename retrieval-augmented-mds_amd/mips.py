@@ -26,6 +26,7 @@ from __future__ import annotations
 import json
 import pickle
 import shutil
+import threading
 from dataclasses import dataclass
 from pathlib import Path
 from random import random
@@ -33,7 +34,7 @@ from random import random
 import numpy as np
 
 from . import _lib
-from .index import MipsIndex, l2_normalize_, rows_max_sumsq
+from .index import MipsIndex, l2_normalize_, rows_max_sumsq, rows_max_sumsq_into
 
 METRIC_INNER_PRODUCT = _lib.METRIC_IP
 METRIC_L2 = _lib.METRIC_L2
@@ -142,6 +143,10 @@ def inner_product(x: np.ndarray, y: np.ndarray, k: int = 1, normalize: bool = Tr
     return s.cpu().numpy(), i.cpu().numpy()
 
 
+_IN_BATCH_INDEXES: dict = {}
+_IN_BATCH_LOCK = threading.Lock()
+
+
 def in_batch_scores(query_cls, mips_cls, normalize: bool = False, dtype: str = "f32"):
     """The in-batch scoring of retriever_lightning.py:304-305 (`scores = query_cls @ mips_cls.T; _, i =
     scores.topk(1)`) and, with normalize=True, of :273-277 (`F.normalize(q) @ F.normalize(d).T`), through the
@@ -160,9 +165,17 @@ def in_batch_scores(query_cls, mips_cls, normalize: bool = False, dtype: str = "
     x = mips_cls.detach().float().contiguous()
     if normalize:
         q, x = l2_normalize_(q.clone()), l2_normalize_(x.clone())
-    ix = MipsIndex(d, metric=METRIC_INNER_PRODUCT, dtype=dtype, device=x.device.index)
-    ix.add(x)
-    s, i = ix.search(q, b)
+    # one small index (+ its scratch) per (device, d, storage), kept for the life of the process: this runs every training /
+    # validation step, and creating and destroying an index is a round of hipMalloc / hipFree that serialises the device
+    key = (x.device.index, int(d), dtype)
+    with _IN_BATCH_LOCK:
+        ix = _IN_BATCH_INDEXES.get(key)
+        if ix is None:
+            ix = _IN_BATCH_INDEXES[key] = MipsIndex(d, metric=METRIC_INNER_PRODUCT, dtype=dtype, device=x.device.index)
+            ix.reserve(_lib.MAX_K)
+        ix.reset()
+        ix.add(x)
+        s, i = ix.search(q, b)
     dense = torch.empty_like(s).scatter_(1, i, s)
     return dense, i[:, 0].contiguous()
 
@@ -442,7 +455,7 @@ class Mips:
                 f"mips_string_factory={self.string_factory!r}: only the exact 'Flat' index is implemented")
         self._building = {"index": MipsIndex(int(d), metric=self.metric_type, dtype=self.args.mips_index_dtype,
                                              device=self.args.mips_device),
-                          "max_sq": 0.0, "cols": {}, "rows": 0}
+                          "max_sq": None, "cols": {}, "rows": 0}   # max_sq: one float64 ON THE DEVICE, read once in end_index_build
 
     def add_embeddings(self, batch, columns: dict = None) -> None:
         """One encoder batch: float32 [n, d] (CUDA tensor straight from the encoder, or NumPy) + its slice of the
@@ -464,7 +477,9 @@ class Mips:
         y = x.to(dev, dtype=torch.float32).contiguous()
         if isinstance(batch, torch.Tensor) and y.data_ptr() == batch.data_ptr():
             y = y.clone()  # the normalisation below is in place; never touch the encoder's tensor
-        b["max_sq"] = max(b["max_sq"], rows_max_sumsq(y))
+        if b["max_sq"] is None:
+            b["max_sq"] = torch.zeros(1, dtype=torch.float64, device=y.device)
+        rows_max_sumsq_into(y, b["max_sq"])   # running maximum on the device: no host copy, no synchronisation per batch
         if self.normalize and self.metric_type == METRIC_INNER_PRODUCT:
             l2_normalize_(y)
         b["index"].add(y)
@@ -477,7 +492,7 @@ class Mips:
         if b is None:
             raise RuntimeError("end_index_build: no build in progress")
         self._building = None
-        self.max_norm = float(np.sqrt(b["max_sq"]))
+        self.max_norm = float(np.sqrt(b["max_sq"].item())) if b["max_sq"] is not None else 0.0   # the build's ONE host copy
         index = b["index"]
         if self.metric_type == METRIC_L2 and index.ntotal > 0:
             self.phi = index.phi()

@@ -929,25 +929,20 @@ def test_f32_exact_two_stage_search(n, nq, d, k, metric):
     s, i = ix.search(q[:5], k)                                    # (bf16 rows are converted lazily: more rows follow)
     ix.add(x[n // 3:])
     s, i = ix.search(q, k)
-    if d <= 768:
-        assert not ix.last_kernel.startswith("mips::scan_kernel<"), ix.last_kernel   # a query-stationary bf16 kernel
-    else:   # pitch 1024: pools of 8 only, stage 1 does not pay by default ...
-        assert ix.last_kernel.startswith("mips::scan_kernel<")
-        ix.set_param("f32_fast", 2)                               # ... but can be asked for
-        s, i = ix.search(q, k)
-        assert not ix.last_kernel.startswith("mips::scan_kernel<")
+    assert not ix.last_kernel.startswith("mips::scan_kernel<"), ix.last_kernel   # a query-stationary bf16 kernel, pitch 1024 included
+    if d > 768:                                                   # (round 3: true K' = 32 lists exist at pitch 1024)
+        assert ix.last_kernel.startswith("mips::scan_kernel_v3<32, 64, 1, 4"), ix.last_kernel
     assert np.array_equal(i, ei) and np.array_equal(s, es)
     st = ix.margin_stats()
     assert st["flagged"] >= 0 and st["rescanned"] == st["flagged"] and st["unresolved"] == 0
     print("two-stage:", n, nq, d, k, metric, ix.last_kernel, st)
-    assert st["flagged"] < (nq // 2 if d > 768 else max(2, nq // 10))   # Gaussian rows: stage 1 certifies nearly all (K' = 32 pools)
+    assert st["flagged"] < max(2, nq // 10)                       # Gaussian rows: stage 1 certifies nearly all (K' = 32 pools)
     qd = torch.from_numpy(q).cuda()
     ix.set_param("f32_fast", 1)
     sd, idd = ix.search(qd, k)                                    # device outputs: two-stage as well, certified on the stream
-    if d <= 768:                                                  # (pitch 1024: pools of 8 flag too much, no stage 1 by default)
-        assert not ix.last_kernel.startswith("mips::scan_kernel<")   # default margin mode: nothing synchronises
-        st_d = ix.margin_stats()
-        assert st_d["rescanned"] == st_d["flagged"] and st_d["unresolved"] == 0
+    assert not ix.last_kernel.startswith("mips::scan_kernel<")   # default margin mode: nothing synchronises
+    st_d = ix.margin_stats()
+    assert st_d["rescanned"] == st_d["flagged"] and st_d["unresolved"] == 0
     assert np.array_equal(idd.cpu().numpy(), ei) and np.array_equal(sd.cpu().numpy(), es)
     ix.set_param("margin_check", 0)                               # no certificate, no two-stage search
     sd, idd = ix.search(qd, k)
@@ -2172,3 +2167,38 @@ def test_real_hf_dataset_reaches_the_index_the_way_the_reference_does(tmp_path, 
         assert np.array_equal(i4, ei) and np.array_equal(s4, es)
     finally:
         sys.modules.pop("faiss", None)
+
+
+@pytest.mark.parametrize("n,nq,d,k", [(60000, 300, 768, 20), (40000, 130, 640, 29), (50000, 300, 1024, 10), (30000, 70, 1000, 25),
+                                       (30000, 40, 1024, 14), (20000, 300, 900, 5)])
+def test_wide_k_pools_and_pitch_1024_lists(n, nq, d, k):
+    """Round 3: (1) k = 14 .. 29 at row pitch 384 .. 768 take the optimistic pools of 32 (16x16x32 kernel, every sub-list vouching
+    for its 4th best) like k = 8 .. 13 did; (2) row pitch 1024 has true K' = 16 / 32 lists on the query-stationary 4-wave kernel:
+    k = 8 .. 29 there, and stage 1 of the two-stage search of an fp32-exact index of Longformer-large width, leave the generic
+    kernel.  Bit-identical to the oracle, host and device call shapes, certified."""
+    x = synth.generate(501, 0, n, d, synth.KIND_GAUSS)
+    q = synth.generate(502, 0, nq, d, synth.KIND_GAUSS)
+    es, ei = orc.search_exact(q, x, k)
+    ix = _index(x)
+    s, i = ix.search(q, k)
+    name = ix.last_kernel
+    if k >= 8 and d <= 768:
+        assert name.startswith("mips::scan_kernel_v4") and name.endswith(", 4>"), name
+    elif k >= 8:
+        assert name.startswith(f"mips::scan_kernel_v3<{16 if k <= 13 else 32}, 64, 1, 4"), name
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+    assert ix.margin_stats()["unresolved"] == 0
+    ds, di = ix.search(torch.from_numpy(q).cuda(), k)
+    assert np.array_equal(di.cpu().numpy(), ei) and np.array_equal(ds.cpu().numpy(), es) and ix.margin_stats()["unresolved"] == 0
+    # the fp32-exact index of the same width: two-stage search with pools of 32 at every pitch
+    rng = np.random.default_rng(n)
+    xf = (x[:20000] * rng.uniform(0.5, 2.0, (20000, 1))).astype(np.float32)
+    qf = (q * rng.uniform(0.5, 2.0, (nq, 1))).astype(np.float32)
+    fs, fi = orc.search_exact(qf, xf, k)
+    f = ram.MipsIndex(d, dtype="f32")
+    f.add(xf)
+    s2, i2 = f.search(torch.from_numpy(qf).cuda(), k)
+    assert not f.last_kernel.startswith("mips::scan_kernel<"), f.last_kernel
+    st = f.margin_stats()
+    assert st["unresolved"] == 0 and st["flagged"] <= max(2, nq // 8), st
+    assert np.array_equal(i2.cpu().numpy(), fi) and np.array_equal(s2.cpu().numpy(), fs)
