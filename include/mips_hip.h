@@ -45,7 +45,9 @@ extern "C" {
 /* element types of caller buffers / of the index storage */
 #define MIPS_DTYPE_F32 0
 #define MIPS_DTYPE_BF16 1
-#define MIPS_DTYPE_FP8_E4M3 2 /* OCP e4m3 bytes: index storage of BASELINE config 5 (d <= 1024, k <= 13) */
+#define MIPS_DTYPE_FP8_E4M3 2 /* OCP e4m3 bytes: index storage AND queries quantised to e4m3, fp8 MFMA (d <= 1024, k <= 13) */
+#define MIPS_DTYPE_FP8_E4M3_DOCS 3 /* index storage only (mips_index_create): OCP e4m3 rows, bf16 QUERIES -- BASELINE config 5 as it is
+                                      worded ("fp8 e4m3 doc embeddings"); d <= 1024 */
 
 /* faiss.METRIC_INNER_PRODUCT / faiss.METRIC_L2 as used by mips.py:306,316,369,371 */
 #define MIPS_METRIC_IP 0
@@ -91,7 +93,12 @@ const char* mips_last_error(void);
  * faiss.IndexFlat(d, metric), sotasum/mips.py:333-340 and retriever_lightning.py:395-404.
  * doc_dtype is the storage type in HBM:
  *   MIPS_DTYPE_BF16      2 B/element, inputs rounded to bf16 (RNE); the fast path
- *   MIPS_DTYPE_FP8_E4M3  1 B/element, inputs AND queries rounded to OCP e4m3 (d <= 1024, k <= 13)
+ *   MIPS_DTYPE_FP8_E4M3  1 B/element, inputs AND queries rounded to OCP e4m3 (d <= 1024, k <= 13): the fp8 MFMA at twice the
+ *                        bf16 rate -- for many queries per pass over the index
+ *   MIPS_DTYPE_FP8_E4M3_DOCS  1 B/element, inputs rounded to OCP e4m3, queries to bf16: half the HBM bytes of a bf16 index with
+ *                        bf16 query precision; the rows are up-converted on their way into the bf16 MFMA
+ *                        (csrc/scan_kernel_e8.hpp), which costs vector instructions -- for FEW queries per pass (<= 64 per tile),
+ *                        where bytes bind.  Canonical score: exact products of (e4m3 row element, bf16 query element), fp64 sum
  *   MIPS_DTYPE_F32       fp32-exact: results are those of an fp32 brute force on the caller's values -- what the Python
  *                        facade (Mips / KnowledgeBase.add_faiss_index / inner_product) creates by default, because the
  *                        reference's embeddings are fp32 and "drop-in" means ITS neighbours

@@ -8,7 +8,7 @@ Everything numeric runs in libmips_hip.so (hand-written HIP for gfx950, csrc/); 
 fallback.  See DESIGN.md and include/mips_hip.h.
 """
 from . import _lib, faiss_shim
-from ._lib import (DTYPE_BF16, DTYPE_F32, IDX_POISON, MAX_K, METRIC_IP, METRIC_L2, SEED_DOCS, SEED_QUERIES, SYNTH_GAUSS,
+from ._lib import (DTYPE_BF16, DTYPE_F32, DTYPE_FP8_E4M3, DTYPE_FP8_E4M3_DOCS, IDX_POISON, MAX_K, METRIC_IP, METRIC_L2, SEED_DOCS, SEED_QUERIES, SYNTH_GAUSS,
                    SYNTH_LATTICE, SYNTH_LATTICE_FP8, build)
 from .index import (MipsIndex, cosine_rescore, filter_ignore, l2_normalize_, merge_topk, merge_topk_packed,
                     rows_max_sumsq, synth_fill)

@@ -21,7 +21,7 @@ HEADER = os.path.join(_ROOT, "include", "mips_hip.h")
 ABI_VERSION = 1
 
 # constants of include/mips_hip.h
-DTYPE_F32, DTYPE_BF16, DTYPE_FP8_E4M3 = 0, 1, 2
+DTYPE_F32, DTYPE_BF16, DTYPE_FP8_E4M3, DTYPE_FP8_E4M3_DOCS = 0, 1, 2, 3
 METRIC_IP, METRIC_L2 = 0, 1
 Q_DEVICE, OUT_DEVICE, OUT_PACKED, FORCE_IP = 1, 2, 4, 8
 SYNTH_LATTICE, SYNTH_GAUSS, SYNTH_LATTICE_FP8 = 0, 1, 2

@@ -629,7 +629,8 @@ __device__ __forceinline__ void rank_flag_write(const MergeArgs& p, int64_t q, i
     }
 }
 
-template <int KL, typename EL, bool L2>
+// ELQ: element type of the staged queries (= EL except for the e4m3-documents / bf16-queries index)
+template <int KL, typename EL, bool L2, typename ELQ = EL>
 __device__ __forceinline__ void rescore_rank_body(const MergeArgs& p, const int* cand, int64_t nq, int64_t wave_index, int lane) {
     constexpr int QPW = 64 / KL; // queries per wave
     const int64_t q = wave_index * QPW + lane / KL;
@@ -653,7 +654,42 @@ __device__ __forceinline__ void rescore_rank_body(const MergeArgs& p, const int*
     const int ci = inq ? cand[(size_t)q * KL + slot] : IDX_NONE;
     const bool valid = ci != IDX_NONE;
     double dot = 0.0, qq = 0.0;
-    if (valid) {
+    if (valid && EL::PER16 != ELQ::PER16) {
+        // e4m3 rows x bf16 queries: one 16-byte chunk of a row (16 elements) meets two of the query (8 each); same sequential
+        // order of the sum as below
+        static_assert(EL::PER16 == ELQ::PER16 || EL::PER16 == 2 * ELQ::PER16, "queries at most twice as wide as the rows");
+        const typename EL::type* x = reinterpret_cast<const typename EL::type*>(p.docs) + (size_t)ci * p.ld;
+        const typename ELQ::type* y = reinterpret_cast<const typename ELQ::type*>(p.qbuf) + (size_t)q * p.ld;
+        constexpr int PF = 12;
+        const int nchunk = p.ld / EL::PER16;
+        u32x4 xr[PF], ya[PF], yb[PF];
+#pragma unroll
+        for (int t = 0; t < PF; ++t) {
+            const int c = t < nchunk ? t : nchunk - 1;
+            xr[t] = *reinterpret_cast<const u32x4*>(x + c * EL::PER16);
+            ya[t] = *reinterpret_cast<const u32x4*>(y + c * EL::PER16);
+            yb[t] = *reinterpret_cast<const u32x4*>(y + c * EL::PER16 + ELQ::PER16);
+        }
+        for (int c0 = 0; c0 < nchunk; c0 += PF) {
+#pragma unroll
+            for (int t = 0; t < PF; ++t) {
+                const u32x4 xv = xr[t], yav = ya[t], ybv = yb[t];
+                const int nx = c0 + PF + t < nchunk ? c0 + PF + t : nchunk - 1;
+                xr[t] = *reinterpret_cast<const u32x4*>(x + nx * EL::PER16);
+                ya[t] = *reinterpret_cast<const u32x4*>(y + nx * EL::PER16);
+                yb[t] = *reinterpret_cast<const u32x4*>(y + nx * EL::PER16 + ELQ::PER16);
+                if (c0 + t < nchunk) {
+#pragma unroll
+                    for (int e = 0; e < EL::PER16; ++e) {
+                        const double xe = (double)EL::get(xv, e);
+                        const double ye = (double)(e < ELQ::PER16 ? ELQ::get(yav, e % ELQ::PER16) : ELQ::get(ybv, e % ELQ::PER16));
+                        dot += xe * ye;
+                        qq += ye * ye;
+                    }
+                }
+            }
+        }
+    } else if (valid) {
         const typename EL::type* x = reinterpret_cast<const typename EL::type*>(p.docs) + (size_t)ci * p.ld;
         const typename EL::type* y = reinterpret_cast<const typename EL::type*>(p.qbuf) + (size_t)q * p.ld;
         constexpr int PF = 24; // 16-byte chunks in flight per row: the kernel is one latency-bound thread per candidate
@@ -687,10 +723,10 @@ __device__ __forceinline__ void rescore_rank_body(const MergeArgs& p, const int*
     rank_flag_write<KL, L2>(p, q, slot, inq, ci, valid, dot, qq, lane);
 }
 
-template <int KL, typename EL, bool L2>
+template <int KL, typename EL, bool L2, typename ELQ = EL>
 __global__ __launch_bounds__(64) void rescore_rank_kernel(MergeArgs p, const int* cand, int64_t nq) {
     if (p.nq_dev != nullptr) nq = *p.nq_dev;
-    rescore_rank_body<KL, EL, L2>(p, cand, nq, (int64_t)blockIdx.x, (int)threadIdx.x);
+    rescore_rank_body<KL, EL, L2, ELQ>(p, cand, nq, (int64_t)blockIdx.x, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------ cross-shard merge (after the all-gather)

@@ -21,6 +21,8 @@
 #include "scan_kernel_v4.hpp"
 #include "scan_kernel_v5.hpp"
 #include "scan_kernel_ks.hpp"
+#include "scan_kernel_k3.hpp"
+#include "scan_kernel_e8.hpp"
 #include "tiny_search.hpp"
 #include "resolve_kernels.hpp"
 
@@ -61,7 +63,7 @@ struct DeviceGuard {
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 constexpr int64_t kRowAlign = 256;   // index capacity granule: the largest document tile of any scan variant
-constexpr int64_t kQueryAlign = 256; // query staging buffer granule: the largest query tile of any scan variant
+constexpr int64_t kQueryAlign = 256; // query staging buffer granule: the largest power-of-two query tile of any scan variant
 
 struct Buffer {
     void* p = nullptr;
@@ -99,6 +101,8 @@ struct mips_index {
     int64_t d = 0;
     int ld = 0;    // row length in elements: d padded to a multiple of 64 (bf16) or 256 (fp8)
     int esize = 2; // bytes per stored element
+    int qsize = 2; // bytes per STAGED query element: esize, except MIPS_DTYPE_FP8_E4M3_DOCS (e4m3 rows, bf16 queries: `mixed`)
+    bool mixed = false;
     int doc_dtype = MIPS_DTYPE_BF16;
     int metric = MIPS_METRIC_IP;
     int64_t ntotal = 0;
@@ -190,6 +194,13 @@ struct mips_index {
 };
 
 namespace {
+
+// Rows the per-query buffers (staged queries, insert bounds, partial lists) are padded to: whole query tiles of every kernel that
+// may take the search -- 256 (128 / 256-query tiles), and at bf16 row pitch 1024 also scan_kernel_k3's 192-query tiles
+inline int64_t query_pad(const mips_index* ix, int64_t n) {
+    const bool pitch_1024 = ix->esize == 2 && (ix->ld == 1024 || ix->hp == 1024);
+    return round_up(n, pitch_1024 ? 768 : kQueryAlign);
+}
 
 // Orders the calls on one index across streams (see mips_index::busy).  Nothing is recorded per call (an event
 // record costs ~5.7 us of stream time here): when a call arrives on ANOTHER stream than the previous one, the
@@ -289,10 +300,12 @@ int grow(mips_index* ix, int64_t need_rows, hipStream_t st, bool exact = false) 
 // convert [n][d] of src_dtype (host or device) into dst [n][ld] of the index element type on the device
 // pad_rows / zero / zero_words: query staging only -- that many zero rows behind the last converted one and a
 // word range to clear, both done by the launch that converts the last chunk (bf16 and fp8 storage)
+// out_esize: bytes per OUTPUT element (0 = the index storage's; query staging passes ix->qsize)
 int convert_into(mips_index* ix, const void* src, int64_t n, int src_dtype, int src_is_device, uint8_t* dst,
                  hipStream_t st, float* keep_f32 = nullptr, int64_t pad_rows = 0, uint32_t* zero = nullptr,
-                 int64_t zero_words = 0) {
+                 int64_t zero_words = 0, int out_esize = 0) {
     const int d = (int)ix->d, ld = ix->ld;
+    if (out_esize == 0) out_esize = ix->esize;
     const size_t esz = src_dtype == MIPS_DTYPE_F32 ? 4 : src_dtype == MIPS_DTYPE_BF16 ? 2 : 1;
     const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(64u << 20) / (int64_t)(d * esz));
     for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
@@ -305,7 +318,7 @@ int convert_into(mips_index* ix, const void* src, int64_t n, int src_dtype, int 
             HIP_TRY(hipMemcpyAsync(ix->stage.p, s, (size_t)nr * d * esz, hipMemcpyHostToDevice, st));
             s = ix->stage.p;
         }
-        uint8_t* out = dst + (size_t)r0 * ld * ix->esize;
+        uint8_t* out = dst + (size_t)r0 * ld * out_esize;
         if (ix->plane > 0) { // fp32-exact mode: bf16 planes [hi | lo] + the fp32 originals
             const int64_t items = nr * (ix->plane / 8);
             float* keep = keep_f32 ? keep_f32 + (size_t)r0 * ix->plane : nullptr;
@@ -318,8 +331,9 @@ int convert_into(mips_index* ix, const void* src, int64_t n, int src_dtype, int 
             const int64_t n_out = nr + (last ? pad_rows : 0);
             uint32_t* z = last ? zero : nullptr;
             const int64_t zw = last ? zero_words : 0;
-            if (ix->esize == 2) {
+            if (out_esize == 2) {
                 const int64_t items = n_out * (ld / 8);
+                if (src_dtype == MIPS_DTYPE_FP8_E4M3) return fail(MIPS_E_INVALID, "e4m3 bytes cannot be staged as bf16 rows");
                 if (src_dtype == MIPS_DTYPE_F32)
                     mips::convert_rows_kernel<float><<<grid_for(items, 256), 256, 0, st>>>((const float*)s, nr, d, (uint16_t*)out, ld, n_out, z, zw);
                 else
@@ -340,8 +354,10 @@ int convert_into(mips_index* ix, const void* src, int64_t n, int src_dtype, int 
     return MIPS_OK;
 }
 
-bool src_dtype_ok(const mips_index* ix, int t) {
-    return t == MIPS_DTYPE_F32 || t == MIPS_DTYPE_BF16 || (t == MIPS_DTYPE_FP8_E4M3 && ix->esize == 1 && ix->plane == 0);
+// for_query: queries of an e4m3-documents / bf16-queries index are float32 or bf16 (raw e4m3 bytes are rows only)
+bool src_dtype_ok(const mips_index* ix, int t, bool for_query = false) {
+    return t == MIPS_DTYPE_F32 || t == MIPS_DTYPE_BF16 ||
+           (t == MIPS_DTYPE_FP8_E4M3 && ix->esize == 1 && ix->plane == 0 && !(for_query && ix->mixed));
 }
 
 int compute_phi(mips_index* ix, hipStream_t st) {
@@ -422,6 +438,31 @@ void swap_scratch_sets(mips_index* ix) {
     ix->cur_set ^= 1;
 }
 
+// scan_kernel_e8 (e4m3 documents x bf16 queries): instance by row pitch, query blocks per tile, ring depth, document cache policy
+template <int PUB>
+int launch_e8(mips_index* ix, const mips::ScanArgsE8& fa, int grid, int ncb, bool nt, hipStream_t st, int slot) {
+    const int stages = ncb == 2 && ix->ld <= 768 ? 4 : 3;
+    const int lds = stages * mips::V3_DB * ix->ld + 8 * (2 * ncb) * 1024 + 2048 + 1024 + 64; // ring + exchange slots + class words + dump + counters
+    auto go = [&](auto kern) -> int {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if (ix->timing_armed) HIP_TRY(hipEventRecord(ix->ev0[slot], st));
+        kern<<<grid, 512, lds, st>>>(fa);
+        return MIPS_OK;
+    };
+#define MIPS_E8_PITCH(LDB)                                                                                            \
+    if (ix->ld == LDB) {                                                                                              \
+        if (ncb == 2) return nt ? go(mips::scan_kernel_e8<6, LDB, 2, (LDB <= 768 ? 4 : 3), true, PUB>)                \
+                                : go(mips::scan_kernel_e8<6, LDB, 2, (LDB <= 768 ? 4 : 3), false, PUB>);              \
+        if constexpr (LDB <= 768) return nt ? go(mips::scan_kernel_e8<6, LDB, 4, 3, true, PUB>) : go(mips::scan_kernel_e8<6, LDB, 4, 3, false, PUB>); \
+    }
+    MIPS_E8_PITCH(256)
+    MIPS_E8_PITCH(512)
+    MIPS_E8_PITCH(768)
+    MIPS_E8_PITCH(1024)
+#undef MIPS_E8_PITCH
+    return fail(MIPS_E_UNSUPPORTED, "e4m3-documents index: no scan instance for row pitch %d with %d query blocks", ix->ld, ncb);
+}
+
 // tail_st: stream of the select + exact re-score launches (nullptr or == st: the scan's own stream)
 template <int KL>
 int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_out_i, int64_t* d_out_packed,
@@ -449,7 +490,15 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     constexpr bool kl_short = KL <= 10; // K' = 8 / 10 lists fit the 8-wave (two per SIMD) configuration
     const bool f8 = ix->esize == 1; // e4m3 index: scan_kernel_f8 only (row lengths 256..1024, K' <= 16)
     const bool f32x = ix->plane > 0; // fp32-exact mode: generic kernel over the [hi | lo] planes, three k segments
-    if (f8) {
+    // e4m3 documents x bf16 queries (MIPS_DTYPE_FP8_E4M3_DOCS): scan_kernel_e8, tiles of 32 queries (up to 32 queries, and at
+    // row pitch 1024) or 64; pools of 8 / 10 / 16 / 32 out of 8 sub-lists of 6 per (query, split), the class words vouching for
+    // 8 PUB documents
+    const bool e8 = ix->mixed;
+    const int e8_ncb = (ix->ld == 1024 || nq <= 32) ? 2 : 4;
+    if (e8) {
+        if (ix->ld % 256 != 0 || ix->ld > 1024) return fail(MIPS_E_UNSUPPORTED, "e4m3-documents index: d must pad to 256/512/768/1024");
+        variant = 3;
+    } else if (f8) {
         if (ix->ld % 256 != 0 || ix->ld > 1024 || KL > 16) return fail(MIPS_E_UNSUPPORTED, "fp8 index: d must pad to 256/512/768/1024 and k <= 13");
         variant = 3;
     } else if (f32x || !v3_dim || (!kl_short && !v3_long && !v4_opt)) {
@@ -461,23 +510,28 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     const int v3_waves = (!f8 && !v4_opt && (ix->ld == 1024 || !kl_short)) ? 4 : 8;
     // fp8: scan_kernel_f8x (16x16x128 MFMA shape, 64-document blocks, 4 sub-lists of 6) for k <= 5 and row pitches
     // up to 768 bytes; scan_kernel_f8 (32x32x64, 32-document blocks) otherwise or when "variant" = 3 asks for it
-    const bool want_f8x = f8 && KL == 8 && ix->ld <= 768 && ix->opt_variant != 3;
+    const bool want_f8x = f8 && !e8 && KL == 8 && ix->ld <= 768 && ix->opt_variant != 3;
+    // scan_kernel_ks (K split over a wave pair, two waves per SIMD): row pitch 1024, k <= 5.  Selectable ("variant" =
+    // 6), not the default: measured 30.6 vs 31.3 ms at 2^22 x 1024 against the one-wave-per-SIMD scan_kernel_v3
+    // configuration (profiles/r2_pitch1024) -- both sit on the L2 -> LDS fill of 128 stationary queries per CU
+    const bool ks_shape = ix->ld == 1024 && KL == 8 && ix->esize == 2 && ix->plane == 0;
+    const bool want_ks = ks_shape && ix->opt_variant == 6;
+    // scan_kernel_k3 (round 3): the wave pairs of scan_kernel_ks with 48 queries each -- 192 stationary queries per CU, a third
+    // less L2 -> LDS fill per flop, which is what bounds pitch 1024.  Default there once several 192-query tiles share the
+    // document stream (the MFMA-bound regime); smaller searches keep the 128-query configuration ("variant" = 7 / 3 force one)
+    const bool want_k3 = ks_shape && ix->opt_sub == 0 && (ix->opt_variant == 7 || (ix->opt_variant == 0 && nq > 256));
+    constexpr int K3_KLL = 4; // entries per sub-list (the third accumulator set is paid for with shorter lists)
     const int tm = variant == 1 ? mips::TM : want_f8x ? mips::F8X_DB : mips::V3_DB; // documents per scheduling unit ("tile")
-    const int tn = variant == 1 ? mips::TN : v3_waves * 32;           // queries per workgroup
+    const int tn = variant == 1 ? mips::TN : e8 ? 16 * e8_ncb : want_k3 ? 192 : v3_waves * 32; // queries per workgroup
     const int wg_target = variant == 1 ? 512 : 256;                   // resident workgroups on 256 CUs
-    const int64_t nq_pad = round_up(nq, kQueryAlign);
+    const int64_t nq_pad = query_pad(ix, nq);
     const int nqt = (int)((nq + tn - 1) / tn);
     // One query tile (round 2): with non-temporal document DMA the 16x16x32 kernel ties scan_kernel_v3 in the HBM-bound
     // regime on large indexes (3.80 vs 3.82 ms at Q = 64 on 2^24 rows), loses 3-8 % on short streams at Q = 8 (0.315 vs
     // 0.304 ms at 2^20 rows, 0.091 vs 0.084 at 2^17) and wins once several waves multiply (3.89 vs 4.15 ms at Q = 128,
     // 5.57 vs 5.98 at Q = 256; profiles/r2_final/ab_single_tile.md): scan_kernel_v3 up to 64 queries, v4 beyond
     const bool want_v4 = !want_v5 && (v4_forced || v4_opt || (v4_auto && (nqt > 1 || nq > 64)));
-    // scan_kernel_ks (K split over a wave pair, two waves per SIMD): row pitch 1024, k <= 5.  Selectable ("variant" =
-    // 6), not the default: measured 30.6 vs 31.3 ms at 2^22 x 1024 against the one-wave-per-SIMD scan_kernel_v3
-    // configuration (profiles/r2_pitch1024) -- both sit on the L2 -> LDS fill of 128 stationary queries per CU
-    const bool ks_shape = ix->ld == 1024 && KL == 8 && ix->esize == 2 && ix->plane == 0;
-    const bool want_ks = ks_shape && ix->opt_variant == 6;
-    const int lists = want_ks ? 8 : (want_v4 || want_v5 || want_f8x) ? 4 : 2;                  // running lists per (query, split)
+    const int lists = (want_ks || want_k3 || e8) ? 8 : (want_v4 || want_v5 || want_f8x) ? 4 : 2; // running lists per (query, split)
     const int ntiles = (int)((ix->ntotal + tm - 1) / tm);
     // Index splits (a multiple of 8: one XCD group each).  The grid nqt x nsplit should come in whole
     // "rounds" of wg_target resident workgroups: among the multiples of 8 up to 64 take the one whose last
@@ -519,7 +573,8 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
 #else
     const bool short_lists = false;
 #endif
-    const size_t ncand = (size_t)nsplit * lists * ((want_v4 || want_v5 || want_ks || want_f8x || short_lists) ? V4_KLL : KL);
+    const int list_len = want_k3 ? K3_KLL : (want_v4 || want_v5 || want_ks || want_f8x || short_lists || e8) ? V4_KLL : KL; // entries per running list
+    const size_t ncand = (size_t)nsplit * lists * list_len;
     int rc = ix->part_s.ensure((size_t)nq_pad * ncand * sizeof(float));
     if (rc) return rc;
     rc = ix->part_i.ensure((size_t)nq_pad * ncand * sizeof(int));
@@ -558,7 +613,24 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
 
     const int grid = qt_per_group * qgroups * nsplit;
     const int slot = ix->ev_next;
-    if (want_ks) {
+    if (e8) {
+        mips::ScanArgsE8 fa;
+        fa.docs = ix->rows;
+        fa.c = a;
+        constexpr int PUB = KL <= 8 ? 1 : KL <= 16 ? 2 : 4;
+        const bool nt = nqt == 1;
+        int rc2 = launch_e8<PUB>(ix, fa, grid, e8_ncb, nt, st, slot);
+        if (rc2) return rc2;
+        set_kernel_name(ix, "mips::scan_kernel_e8<6, %d, %d, %d, %s, %d>", ix->ld, e8_ncb, e8_ncb == 2 && ix->ld <= 768 ? 4 : 3, nt ? "true" : "false", PUB);
+    } else if (want_k3) {
+        if constexpr (KL == 8) {
+            const int lds = 2 * mips::V3_DB * ix->ld * 2 + 4 * 1536 + 8 * 3072 + 64; // ring + the pairs' class-word copies + exchange slots + counters
+            HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel_k3<K3_KLL, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            if (ix->timing_armed) HIP_TRY(hipEventRecord(ix->ev0[slot], st));
+            mips::scan_kernel_k3<K3_KLL, 32, 2><<<grid, 512, lds, st>>>(a);
+            set_kernel_name(ix, "mips::scan_kernel_k3<%d, 32, 2, 0>", K3_KLL);
+        }
+    } else if (want_ks) {
         if constexpr (KL == 8) {
             const int lds = 2 * mips::V3_DB * ix->ld * 2 + 8 * 1024 + 8 * 2048 + 64; // ring + class-word copies + exchange slots + counters
             HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel_ks<V4_KLL, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -600,6 +672,9 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             const bool nt = nqt == 1 && ix->opt_sub != 30; // one query tile: every document block has a single reader
 #ifdef MIPS_EXPERIMENTAL
             if (ix->ld == 768 && ix->opt_sub == 8) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 1>); // timing only: no epilogue
+            else if (ix->ld == 768 && ix->opt_sub == 43) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 3>); // static priority for waves 4 .. 7
+            else if (ix->ld == 768 && ix->opt_sub == 44) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 4>); // s_nop arrival poll
+            else if (ix->ld == 768 && ix->opt_sub == 45) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 5>); // both
             else
 #endif
             if (v4_opt) { // pools of 16 / 32: every sub-list vouches for its 4th best (8 x 4 = 32 documents above the bound)
@@ -794,7 +869,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     m.out_packed = d_out_packed;
     m.err = a.err;
     m.sticky = ix->sticky_dev;
-    m.ll = (want_v4 || want_v5 || want_ks || want_f8x || short_lists) ? V4_KLL : KL;
+    m.ll = list_len;
     m.pre_bnd = nullptr;
     m.npre = 0;
     m.bnd = nullptr;
@@ -848,6 +923,8 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     const int rgrid = (int)((nq + (64 / KL) - 1) / (64 / KL));
     if (f32r && l2) mips::rescore_rank_kernel<KL, mips::ElemF32, true><<<rgrid, 64, 0, st>>>(m, cand, nq);
     else if (f32r) mips::rescore_rank_kernel<KL, mips::ElemF32, false><<<rgrid, 64, 0, st>>>(m, cand, nq);
+    else if (e8 && l2) mips::rescore_rank_kernel<KL, mips::ElemF8, true, mips::ElemBF16><<<rgrid, 64, 0, st>>>(m, cand, nq);
+    else if (e8) mips::rescore_rank_kernel<KL, mips::ElemF8, false, mips::ElemBF16><<<rgrid, 64, 0, st>>>(m, cand, nq);
     else if (f8 && l2) mips::rescore_rank_kernel<KL, mips::ElemF8, true><<<rgrid, 64, 0, st>>>(m, cand, nq);
     else if (f8) mips::rescore_rank_kernel<KL, mips::ElemF8, false><<<rgrid, 64, 0, st>>>(m, cand, nq);
     else if (l2) mips::rescore_rank_kernel<KL, mips::ElemBF16, true><<<rgrid, 64, 0, st>>>(m, cand, nq);
@@ -1101,6 +1178,7 @@ int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
         return MIPS_OK;
     };
     if (f32x) rc = l2 ? go(mips::exact_filter_kernel<mips::ElemF32, true>) : go(mips::exact_filter_kernel<mips::ElemF32, false>);
+    else if (ix->mixed) rc = l2 ? go(mips::exact_filter_kernel<mips::ElemF8, true, mips::ElemBF16>) : go(mips::exact_filter_kernel<mips::ElemF8, false, mips::ElemBF16>);
     else if (ix->esize == 1) rc = l2 ? go(mips::exact_filter_kernel<mips::ElemF8, true>) : go(mips::exact_filter_kernel<mips::ElemF8, false>);
     else rc = l2 ? go(mips::exact_filter_kernel<mips::ElemBF16, true>) : go(mips::exact_filter_kernel<mips::ElemBF16, false>);
     if (rc) return rc;
@@ -1140,8 +1218,8 @@ int rescan_on_stream(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i
         ix->last_max_n = 0;
     }
     if (wide == 0) return MIPS_OK; // already on the widest lists: counted only
-    const int64_t n_pad = round_up(nq, kQueryAlign);
-    const size_t row_bytes = (size_t)ix->ld * ix->esize;
+    const int64_t n_pad = query_pad(ix, nq);
+    const size_t row_bytes = (size_t)ix->ld * ix->qsize;
     int rc = ix->ids.ensure((size_t)(nq + 4) * sizeof(int));
     if (rc) return rc;
     int* ids = (int*)ix->ids.p;
@@ -1263,8 +1341,8 @@ int finish_margin(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i, b
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(ix->ids.p, ids_h, (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
     const int* ids = (const int*)ix->ids.p;
-    const int64_t n_pad = round_up(n, kQueryAlign);
-    const size_t row_bytes = (size_t)ix->ld * ix->esize;
+    const int64_t n_pad = query_pad(ix, n);
+    const size_t row_bytes = (size_t)ix->ld * ix->qsize;
     rc = ix->qbuf2.ensure((size_t)n_pad * row_bytes);
     if (rc) return rc;
     mips::gather_rows_kernel<<<grid_for(n_pad * (int64_t)(row_bytes / 16), 256), 256, 0, st>>>((const unsigned char*)ix->qbuf.p, ids, n, n_pad,
@@ -1394,9 +1472,10 @@ int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, 
     if (d <= 0 || d > (1 << 20)) return fail(MIPS_E_INVALID, "mips_index_create: bad dimension %lld", (long long)d);
     if (metric != MIPS_METRIC_IP && metric != MIPS_METRIC_L2)
         return fail(MIPS_E_INVALID, "mips_index_create: metric must be 0 (inner product) or 1 (L2), got %d", metric);
-    if (doc_dtype != MIPS_DTYPE_BF16 && doc_dtype != MIPS_DTYPE_FP8_E4M3 && doc_dtype != MIPS_DTYPE_F32)
-        return fail(MIPS_E_INVALID, "mips_index_create: index storage dtype must be BF16, FP8_E4M3 or F32, got %d", doc_dtype);
-    if (doc_dtype == MIPS_DTYPE_FP8_E4M3 && d > 1024)
+    if (doc_dtype != MIPS_DTYPE_BF16 && doc_dtype != MIPS_DTYPE_FP8_E4M3 && doc_dtype != MIPS_DTYPE_F32 && doc_dtype != MIPS_DTYPE_FP8_E4M3_DOCS)
+        return fail(MIPS_E_INVALID, "mips_index_create: index storage dtype must be BF16, FP8_E4M3, FP8_E4M3_DOCS or F32, got %d", doc_dtype);
+    const bool f8_storage = doc_dtype == MIPS_DTYPE_FP8_E4M3 || doc_dtype == MIPS_DTYPE_FP8_E4M3_DOCS;
+    if (f8_storage && d > 1024)
         return fail(MIPS_E_UNSUPPORTED, "mips_index_create: fp8 e4m3 storage supports d <= 1024 in this build");
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
@@ -1407,11 +1486,13 @@ int mips_index_create(mips_index_t** out, int device, int64_t d, int doc_dtype, 
     if (!ix) return fail(MIPS_E_NOMEM, "out of host memory");
     ix->device = device;
     ix->d = d;
-    ix->esize = doc_dtype == MIPS_DTYPE_FP8_E4M3 ? 1 : 2;
+    ix->esize = f8_storage ? 1 : 2;
+    ix->mixed = doc_dtype == MIPS_DTYPE_FP8_E4M3_DOCS;
+    ix->qsize = ix->mixed ? 2 : ix->esize;
     // Row pitch.  bf16: the query-stationary kernels exist for pitches of 128 .. 768 (multiples of 128) and
     // 1024, so every d <= 1024 is padded to one of those (zero columns); beyond that the generic kernel
     // takes multiples of 64.  fp8: multiples of 256 bytes.  fp32-exact: generic kernel over two planes.
-    if (doc_dtype == MIPS_DTYPE_FP8_E4M3) ix->ld = (int)round_up(d, 256);
+    if (f8_storage) ix->ld = (int)round_up(d, 256);
     else if (doc_dtype == MIPS_DTYPE_F32 || d > 1024) ix->ld = (int)round_up(d, mips::BK);
     else ix->ld = d > 768 ? 1024 : (int)round_up(d, 128);
     if (doc_dtype == MIPS_DTYPE_F32) {
@@ -1659,7 +1740,7 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
     if (!ix) return fail(MIPS_E_INVALID, "mips_search: index is NULL");
     if (nq < 0 || k < 0) return fail(MIPS_E_INVALID, "mips_search: negative nq or k");
     if (k > MIPS_MAX_K) return fail(MIPS_E_UNSUPPORTED, "mips_search: k = %d exceeds MIPS_MAX_K = %d", k, MIPS_MAX_K);
-    if (!src_dtype_ok(ix, q_dtype)) return fail(MIPS_E_INVALID, "mips_search: q_dtype must be F32 or BF16 (or FP8_E4M3 bytes for an fp8 index)");
+    if (!src_dtype_ok(ix, q_dtype, true)) return fail(MIPS_E_INVALID, "mips_search: q_dtype must be F32 or BF16 (or FP8_E4M3 bytes for an all-e4m3 index)");
     if (nq == 0 || k == 0) return MIPS_OK;
     if (!q || !out_idx || (!out_scores && !(flags & MIPS_OUT_PACKED))) return fail(MIPS_E_INVALID, "mips_search: NULL buffer");
     if (nq > (1 << 24)) return fail(MIPS_E_UNSUPPORTED, "mips_search: more than 2^24 queries in one call");
@@ -1734,8 +1815,8 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
             int rc = compute_phi(ix, st);
             if (rc) return rc;
         }
-        const int64_t nq_pad = round_up(nq, kQueryAlign);
-        const size_t row_bytes = (size_t)ix->ld * ix->esize;
+        const int64_t nq_pad = query_pad(ix, nq);
+        const size_t row_bytes = (size_t)ix->ld * ix->qsize;
         int rc = ix->qbuf.ensure((size_t)nq_pad * row_bytes);
         if (rc) return rc;
         uint8_t* qb = (uint8_t*)ix->qbuf.p;
@@ -1756,7 +1837,7 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
             HIP_TRY(hipMemsetAsync(ix->gthr.p, 0, (size_t)thr_words * sizeof(unsigned), st));
         } else { // one launch converts the queries, zero-pads to the tile multiple and clears the bounds
             rc = convert_into(ix, q, nq, q_dtype, (flags & MIPS_Q_DEVICE) ? 1 : 0, qb, st, qkeep, nq_pad - nq,
-                              (uint32_t*)ix->gthr.p, thr_words);
+                              (uint32_t*)ix->gthr.p, thr_words, ix->qsize);
             if (rc) return rc;
         }
         // The MFMA scores only SELECT a pool of K' candidates that is then re-scored exactly.
@@ -1773,7 +1854,10 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
         const bool hi_long = ix->hp > 0 && ix->hp <= 1024;
         // (round 3: row pitch 1024 has true K' = 32 lists as well -- with pools of 8, all it had before, 46 % of a Gaussian
         // test set went to the second stage and stage 1 did not pay)
-        bool fast = ix->plane > 0 && ix->hp > 0 && hi_long && ix->opt_f32_fast != 0 && ix->opt_margin != 0 && !split &&
+        // k <= 13 only: the pool is 32 wide whatever k, and the widened margin (representation error of bf16(x) . bf16(q)) has to
+        // fit between the k-th and the 33rd score -- at k = 20 .. 29 nearly every query of a Gaussian test set was flagged, and an
+        // exact pass per 8 flagged queries costs far more than the three-segment scan saves
+        bool fast = ix->plane > 0 && ix->hp > 0 && hi_long && k <= 13 && ix->opt_f32_fast != 0 && ix->opt_margin != 0 && !split &&
                     (ix->opt_f32_fast == 2 || !out_dev || ix->opt_margin >= 2);
         if (fast && ix->opt_f32_fast == 1 && ix->fast_skip > 0) {
             --ix->fast_skip;
@@ -1834,7 +1918,7 @@ int mips_search_fused(mips_index_t* ix, const void* q_device, int q_dtype, int64
     if (nq < 0 || k < 0) return fail(MIPS_E_INVALID, "mips_search_fused: negative nq or k");
     const int k_fetch = k + (ignore_device ? 1 : 0);
     if (k_fetch > MIPS_MAX_K) return fail(MIPS_E_UNSUPPORTED, "mips_search_fused: k = %d exceeds MIPS_MAX_K = %d", k_fetch, MIPS_MAX_K);
-    if (!src_dtype_ok(ix, q_dtype)) return fail(MIPS_E_INVALID, "mips_search_fused: q_dtype must be F32 or BF16");
+    if (!src_dtype_ok(ix, q_dtype, true)) return fail(MIPS_E_INVALID, "mips_search_fused: q_dtype must be F32 or BF16");
     if (normalize && q_dtype != MIPS_DTYPE_F32) return fail(MIPS_E_INVALID, "mips_search_fused: normalize needs float32 queries");
     if (nq == 0 || k == 0) return MIPS_OK;
     if (!q_device || !out_idx_device || !out_scores_device) return fail(MIPS_E_INVALID, "mips_search_fused: NULL buffer");

@@ -66,7 +66,8 @@ __device__ __forceinline__ float resolve_key(double dot, double qq, double phi) 
 
 // RESOLVE_WAVES waves; wave w of workgroup b owns rows (b * RESOLVE_WAVES + w) * 64 .. + 63 of each grid stride
 // (8 waves = two per SIMD: one wave alone cannot cover the LDS round trips between its fp64 chains)
-template <typename EL, bool L2>
+// ELQ: element type of the staged queries (= EL except for the e4m3-documents / bf16-queries index)
+template <typename EL, bool L2, typename ELQ = EL>
 __global__ __launch_bounds__(64 * RESOLVE_WAVES) void exact_filter_kernel(ResolveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n = *a.n_dev;
@@ -79,17 +80,19 @@ __global__ __launch_bounds__(64 * RESOLVE_WAVES) void exact_filter_kernel(Resolv
     u32x4* tile = reinterpret_cast<u32x4*>(tiles) + wave * 64 * (TCH + 1);
     const int nchunk = a.ld / PER;               // 16-byte chunks per row, a multiple of TCH
     const typename EL::type* rows = reinterpret_cast<const typename EL::type*>(a.rows);
-    const typename EL::type* ys = reinterpret_cast<const typename EL::type*>(a.y);
+    const typename ELQ::type* ys = reinterpret_cast<const typename ELQ::type*>(a.y);
+    constexpr int PERQ = ELQ::PER16;
+    const int nchunkq = a.ld / PERQ;
 
     for (int j0 = 0; j0 < n; j0 += RESOLVE_QB) {
         __syncthreads(); // (the previous batch's queries are no longer read)
         // the batch's queries -> fp64 in LDS (rows past n: zeros)
-        for (int t = tid; t < RESOLVE_QB * nchunk; t += 64 * RESOLVE_WAVES) {
-            const int j = t / nchunk, c = t % nchunk;
+        for (int t = tid; t < RESOLVE_QB * nchunkq; t += 64 * RESOLVE_WAVES) {
+            const int j = t / nchunkq, c = t % nchunkq;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (j0 + j < n) v = *reinterpret_cast<const u32x4*>(ys + (size_t)a.ids[j0 + j] * a.ld + (size_t)c * PER);
+            if (j0 + j < n) v = *reinterpret_cast<const u32x4*>(ys + (size_t)a.ids[j0 + j] * a.ld + (size_t)c * PERQ);
 #pragma unroll
-            for (int e = 0; e < PER; ++e) yd[(size_t)j * a.ld + c * PER + e] = j0 + j < n ? (double)EL::get(v, e) : 0.0;
+            for (int e = 0; e < PERQ; ++e) yd[(size_t)j * a.ld + c * PERQ + e] = j0 + j < n ? (double)ELQ::get(v, e) : 0.0;
         }
         __syncthreads();
         float kk[RESOLVE_QB];

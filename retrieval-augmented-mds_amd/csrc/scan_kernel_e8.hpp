@@ -1,0 +1,308 @@
+// scan_kernel_e8: e4m3 DOCUMENTS x bf16 QUERIES -- BASELINE config 5 as it is worded ("fp8 e4m3 doc embeddings").
+//
+// The other fp8 kernels (scan_kernel_f8 / f8x) quantise the queries to e4m3 as well and run the fp8 MFMA at twice the bf16
+// rate; here only the index is e4m3 -- half the HBM bytes of a bf16 index -- and the queries stay bf16: every product
+// (e4m3 document element) x (bf16 query element) is exact in fp32, the MFMA accumulates in fp32, and the canonical score the
+// results are re-scored with is the sequential fp64 sum of those exact products (oracle: search_exact on the decoded rows and the
+// bf16-rounded queries).  It is meant for the regime where BYTES bind -- few queries per pass over the index -- so it is built
+// around the conversion e4m3 -> bf16, which costs vector instructions (8 per 16 x 32 A fragment: 4 v_cvt_pk_f32_fp8 + 4
+// v_perm_b32; e4m3 -> bf16 is exact), not around MFMA throughput:
+//   * the 8 waves of a workgroup split K, not the queries: wave w multiplies columns [w K/8, (w + 1) K/8) of a 32-document
+//     block against ALL the tile's queries (16 NCB <= 64), so every A fragment is read from LDS and converted ONCE per block
+//     (a query-split kernel would convert it once per wave: 8 x the vector work, VALU-bound at a third of the HBM rate);
+//   * the partial sums (2 document halves x NCB query blocks x 16 x 16 per wave) meet in LDS: every wave writes its 2 NCB
+//     accumulator tiles to its slot, a block barrier, then wave w sums tile w over the 8 slots IN SLOT ORDER (the MFMA score is
+//     the same number whoever asks) and runs scan_kernel_v4's top-K epilogue on it -- one sub-list of KL = 6 per lane, 8
+//     sub-lists per (query, split): 2 halves x 4 lane groups;
+//   * the ring holds RAW e4m3 blocks (32 rows x K bytes: 24 KiB at K = 768), so 3-4 stages are in flight per CU where a bf16
+//     block of the same documents would be 48 KiB -- the point of the exercise; LDS image, XOR swizzle and LDS-DMA pieces are
+//     scan_kernel_v4's with 128-BYTE slabs (128 k instead of 64); lane (c, g) reads the 8 bytes of row c, k = 32 s + 8 g with
+//     one ds_read_b64 (conflict-free: 16-byte chunk slot = chunk ^ ((row >> 1) & 7), the two 8-byte halves side by side);
+//   * two counter barriers per block in LDS (inline asm, bounded polls): A = everybody's share of the block has landed and
+//     everybody is done with the previous block's slots, B = everybody's partial sums are written.
+// Shared insert bounds: 8 class words per query, class (4 split + g) & 7, as scan_kernel_v4; every sub-list publishes its PUB-th
+// best, so the words vouch for 8 PUB documents: PUB = 1 for pools of 8, 2 for pools of 10 / 16, 4 for pools of 32 (the margin
+// check decides per query whether a pool selected from sub-lists of 6 was wide enough, as for scan_kernel_v4's optimistic pools).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "scan_kernel.hpp"
+#include "scan_kernel_v3.hpp"
+#include "scan_kernel_v4.hpp"
+
+namespace mips {
+
+struct ScanArgsE8 {
+    const uint8_t* docs;  // [capacity][ld] e4m3 bytes
+    ScanArgs c;           // qbuf = bf16 queries [nq_pad][ld]; everything else as for the bf16 kernels
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// 8 e4m3 bytes (two dwords, element j in byte j) -> 8 bf16 (exact)
+__device__ __forceinline__ bf16x8 e4m3x8_to_bf16x8(unsigned lo, unsigned hi) {
+    u32x4 w = {0u, 0u, 0u, 0u};
+#if defined(__HIP_DEVICE_COMPILE__)
+    const f32x2 f01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), f23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
+    const f32x2 f45 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), f67 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
+    // v_perm_b32: D = {S0.hi16, S1.hi16}: the bf16 of an e4m3 value is the upper half of its float32 (<= 4 significant bits)
+    w[0] = __builtin_amdgcn_perm(__float_as_uint(f01[1]), __float_as_uint(f01[0]), 0x07060302u);
+    w[1] = __builtin_amdgcn_perm(__float_as_uint(f23[1]), __float_as_uint(f23[0]), 0x07060302u);
+    w[2] = __builtin_amdgcn_perm(__float_as_uint(f45[1]), __float_as_uint(f45[0]), 0x07060302u);
+    w[3] = __builtin_amdgcn_perm(__float_as_uint(f67[1]), __float_as_uint(f67[0]), 0x07060302u);
+#else
+    (void)lo; (void)hi;
+#endif
+    bf16x8 r;
+    __builtin_memcpy(&r, &w, 16);
+    return r;
+}
+
+// KL: entries per sub-list; LDB: row pitch in bytes = padded K (256 .. 1024); NCB: 16-query column blocks per tile (2 or 4);
+// STAGES: ring depth; NT_DOCS: non-temporal document DMA (one query tile: every block has a single reader)
+template <int KL, int LDB, int NCB, int STAGES, bool NT_DOCS, int PUB = 1>
+__global__ __launch_bounds__(512, 2) void scan_kernel_e8(ScanArgsE8 pa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const ScanArgs& p = pa.c;
+    constexpr int WAVES = 8;
+    constexpr int TN = 16 * NCB;                    // queries per workgroup
+    constexpr int KS = LDB / 256;                   // k32-steps per wave (K / 8 columns)
+    constexpr int STAGE_BYTES = V3_DB * LDB;        // 32 rows x K bytes
+    constexpr int PIECES = STAGE_BYTES / 1024;
+    constexpr int PPW = PIECES / WAVES;
+    constexpr int TILES = 2 * NCB;                  // 16 x 16 accumulator tiles per block: (document half, query block)
+    static_assert(LDB % 256 == 0 && LDB >= 256 && LDB <= 1024, "row pitch");
+    static_assert(PIECES % WAVES == 0, "every wave issues the same number of DMA pieces");
+    static_assert(TILES <= WAVES, "one reducing wave per accumulator tile");
+    static_assert(KL <= 8 && STAGES >= 3 && PUB >= 1 && PUB <= KL, "");
+
+    // ---- LDS map: ring | exchange slots [wave][tile][64 lanes][4 floats] | class words of the tile's queries (+ dump) | counters
+    constexpr unsigned XCH_AREA = STAGES * STAGE_BYTES;
+    constexpr unsigned XCH_WAVE = TILES * 1024u;
+    constexpr unsigned THR_AREA = XCH_AREA + WAVES * XCH_WAVE;   // 16 NCB queries x 32 B (<= 2 KiB), refreshed by wave 0
+    constexpr unsigned THR_BYTES = TN * 32u;
+    constexpr unsigned DUMP_AREA = THR_AREA + 2048u;             // 1 KiB: where the dummy refresh "lands"
+    constexpr unsigned CNT_AREA = DUMP_AREA + 1024u;
+    static_assert(CNT_AREA + 64 <= 160 * 1024, "LDS budget");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15;
+    const int g = lane >> 4;
+
+    const int xcd = blockIdx.x & 7;
+    const int j0 = blockIdx.x >> 3;
+    const int qt = (xcd % p.qgroups) + p.qgroups * (j0 % p.qt_per_group);
+    const int split = (xcd / p.qgroups) * p.splits_per_group + j0 / p.qt_per_group;
+    if (qt >= p.nqt) return;
+    if (p.spin_limit < 0 && tid == 0) *p.err = 1u; // test-only: force the scan-error path (include/mips_hip.h, "spin_limit")
+
+    const int b0 = split * p.tiles_per_split;
+    int b1 = b0 + p.tiles_per_split;
+    if (b1 > p.ntiles) b1 = p.ntiles;
+    const int nb = b1 > b0 ? b1 - b0 : 0;
+
+    // ---- stationary query fragments of this wave's K slice: lane holds Q[q0 + 16 n + c][32 (KS wave + j) + 8 g .. +8)
+    bf16x8 bq[NCB][KS];
+#pragma unroll
+    for (int n = 0; n < NCB; ++n) {
+        const uint16_t* qrow = p.qbuf + ((int64_t)qt * TN + n * 16 + c) * p.ld + 32 * KS * wave + 8 * g;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) bq[n][j] = *reinterpret_cast<const bf16x8*>(qrow + 32 * j);
+    }
+
+    // the one sub-list of this lane: documents 4 g .. 4 g + 3 of half `th` against query 16 tn + c (waves >= TILES keep none)
+    const int th = wave / NCB, tn = wave % NCB;
+    const bool reducer = wave < TILES;
+    float ls[KL];
+    int li[KL];
+    float thr = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < KL; ++i) {
+        ls[i] = -INFINITY;
+        li[i] = IDX_NONE;
+    }
+
+    // ---- shared insert bounds: p.gthr = [query][8 words]; the tile's TN queries are THR_BYTES contiguous bytes
+    const __amdgpu_buffer_rsrc_t thr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<unsigned char*>(p.gthr) + (int64_t)qt * THR_BYTES), 0, (int)THR_BYTES, 0x00020000);
+    for (int t = tid; t < (int)(THR_BYTES / 16u); t += 512) *reinterpret_cast<uint4*>(smem + THR_AREA + t * 16) = make_uint4(0u, 0u, 0u, 0u);
+    // every wave issues ONE such operation per block (uniform vmcnt arithmetic): when `real`, wave w < THR_PIECES brings KiB w of
+    // the tile's class words; lanes past the words, and every lane of the other waves, point out of range (no memory access,
+    // zeros into the dump area).  Readers never wait for these: a word that has not arrived yet is merely an older, weaker bound.
+    constexpr int THR_PIECES = (int)((THR_BYTES + 1023u) / 1024u);
+    static_assert(THR_PIECES <= 2, "");
+    auto refresh_thresholds = [&](bool real) {
+        const unsigned ln = lane_id_here();
+        const bool mine = real && wave < THR_PIECES;
+        const unsigned at = (unsigned)wave * 1024u + ln * 16u;
+        lds_void* dst = (lds_void*)(smem + (mine ? THR_AREA + (unsigned)wave * 1024u : DUMP_AREA));
+        const unsigned voff = (mine && at < THR_BYTES) ? at : (0x40000000u | (ln * 16u));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rsrc, dst, 16, voff, 0, 0, 16);
+    };
+
+    // ---- LDS-DMA map (scan_kernel_v4's with 128-byte slabs): piece pc = slab * 4 + rg = rows 8 rg .. + 7 of slab `slab`
+    const unsigned char* docs_b = pa.docs;
+    constexpr int row_bytes = LDB;
+    auto issue_piece = [&](const unsigned char* blk_base, int stage, int i) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)blk_base, 0, V3_DB * row_bytes, 0x00020000);
+        const int pc = wave + WAVES * i;
+        const int slab = pc >> 2, rg = pc & 3;
+        const unsigned ln = lane_id_here();
+        const unsigned lane_off0 = (ln >> 3) * (unsigned)row_bytes + (((ln & 7u) ^ ((ln >> 4) & 7u)) << 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + stage * STAGE_BYTES + pc * 1024), 16,
+                                                 (rg & 1) ? (lane_off0 ^ 64u) : lane_off0, rg * 8 * row_bytes + slab * 128, 0, NT_DOCS ? 2 : 0);
+    };
+    constexpr int PER_BLOCK = PPW + 1; // VMEM operations per wave and block: its pieces + one threshold operation
+
+    // ---- counter barriers in LDS (inline asm: see scan_kernel_v3.hpp, "split barrier")
+    const unsigned cnt_a = (unsigned)(size_t)(lds_void*)(smem + CNT_AREA), cnt_b = cnt_a + 16u;
+    auto bump = [&](unsigned addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (lane_id_here() == 0u) asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
+#endif
+    };
+    auto poll = [&](unsigned addr, unsigned need) {
+        for (int spin = 0;; ++spin) {
+            unsigned v = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+#endif
+            if (__builtin_amdgcn_readfirstlane(v) >= need) break;
+            if (spin > p.spin_limit) {
+                if (lane == 0) *p.err = 1u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+
+    const unsigned char* first = docs_b + (int64_t)b0 * V3_DB * row_bytes;
+    const unsigned char* last = docs_b + (int64_t)(b1 - 1) * V3_DB * row_bytes;
+    constexpr int64_t blk_bytes = (int64_t)V3_DB * row_bytes;
+    constexpr int AHEAD = STAGES - 1;
+    if (tid < 16) reinterpret_cast<unsigned*>(smem + CNT_AREA)[tid] = 0u;
+    if (nb > 0) {
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a) { // same operation sequence as steady-state blocks (vmcnt arithmetic)
+            refresh_thresholds(true);
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) issue_piece(a < nb ? first + a * blk_bytes : last, a, i);
+        }
+    }
+    __syncthreads();
+    const unsigned char* pbase = nb > AHEAD ? first + AHEAD * blk_bytes : last;
+    int stage = 0, pstage = AHEAD;
+    for (int i = 0; i < nb; ++i) {
+        const int blk = b0 + i;
+        const bool refresh = i < 8 || (i & 7) == 0;
+        // barrier A: this wave's share of block i has landed (everything but the youngest AHEAD - 1 blocks' operations) ...
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PER_BLOCK) : "memory");
+        bump(cnt_a);
+        poll(cnt_a, (unsigned)(i + 1) * WAVES); // ... and everybody's; everybody is also done with block i - 1 (its stage, the slots)
+        // block i + AHEAD goes into the stage block i - 1 just left
+        refresh_thresholds(refresh);
+#pragma unroll
+        for (int t = 0; t < PPW; ++t) issue_piece(pbase, pstage, t);
+
+        // ---- this wave's K slice of the block: convert + multiply
+        const unsigned char* sa = smem + stage * STAGE_BYTES;
+        f32x4 acc[2][NCB];
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int n = 0; n < NCB; ++n) acc[half][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const unsigned ln = lane_id_here();
+            const unsigned cc = ln & 15u, gg = ln >> 4;
+            const unsigned rowoff = cc * 128u + 8u * (gg & 1u);
+            const unsigned swz = (cc >> 1) & 7u;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                const int sg = KS * wave + j;              // global k32-step (wave-uniform)
+                const unsigned chunk = 2u * (unsigned)(sg & 3) + (gg >> 1);
+                const unsigned off = (unsigned)(sg >> 2) * 4096u + rowoff + ((chunk ^ swz) << 4);
+                // (inline asm: behind an ordinary load of an LDS-DMA destination hipcc first drains vmcnt(0) -- the whole ring)
+                uint2 raw[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+#if defined(__HIP_DEVICE_COMPILE__)
+                {
+                    const unsigned a0 = (unsigned)(size_t)(lds_void*)sa + off;
+                    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:2048\n\ts_waitcnt lgkmcnt(0)" : "=&v"(raw[0]), "=&v"(raw[1]) : "v"(a0) : "memory");
+                }
+#endif
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const bf16x8 af = e4m3x8_to_bf16x8(raw[half].x, raw[half].y);
+#pragma unroll
+                    for (int n = 0; n < NCB; ++n) acc[half][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bq[n][j], acc[half][n], 0, 0, 0);
+                }
+            }
+            // ---- partial sums -> this wave's slot
+            unsigned char* slot = smem + XCH_AREA + wave * XCH_WAVE + ln * 16u;
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int n = 0; n < NCB; ++n) *reinterpret_cast<f32x4*>(slot + (half * NCB + n) * 1024) = acc[half][n];
+        }
+        bump(cnt_b); // (a wave's LDS operations complete in order: the counter is visible after the slot)
+        if (reducer) {
+            poll(cnt_b, (unsigned)(i + 1) * WAVES);
+            const unsigned ln = lane_id_here();
+            const unsigned char* src = smem + XCH_AREA + (unsigned)wave * 1024u + ln * 16u; // tile `wave` of every slot
+            f32x4 sum = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) sum = sum + *reinterpret_cast<const f32x4*>(src + w * XCH_WAVE); // slot order
+            if (refresh) { // minimum of the 8 class words of query 16 tn + c (what an earlier refresh brought, or 0)
+                const unsigned a0 = (unsigned)(size_t)(lds_void*)smem + THR_AREA + ((unsigned)tn * 16u + (ln & 15u)) * 32u;
+                u32x4 w0 = {0u, 0u, 0u, 0u}, w1 = w0;
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(w0), "=&v"(w1) : "v"(a0) : "memory");
+#endif
+                const unsigned key = min(min(min(w0[0], w0[1]), min(w0[2], w0[3])), min(min(w1[0], w1[1]), min(w1[2], w1[3])));
+                thr = fmaxf(thr, key > 1u ? thr_decode(key - 1u) : -INFINITY);
+            }
+            const int base = blk * V3_DB + 16 * th + 4 * (int)(ln >> 4);
+            if ((int64_t)(blk + 1) * V3_DB > p.ntotal) { // ragged last block of the index (uniform)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if ((int64_t)(base + r) >= p.ntotal) sum[r] = -INFINITY;
+            }
+            const float mx = fmaxf(fmaxf(sum[0], sum[1]), fmaxf(sum[2], sum[3]));
+            if (__ballot(mx > thr) != 0ull) {
+                const float mark = ls[PUB - 1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s = sum[r];
+                    if (s > thr) {
+                        list_insert<KL>(ls, li, s, base + r);
+                        thr = fmaxf(thr, ls[KL - 1]);
+                    }
+                }
+                if (ls[PUB - 1] > mark) { // new PUB-th best of this sub-list: raise its class word, (4 split + g) & 7
+                    const unsigned cls = (4u * (unsigned)split + (ln >> 4)) & 7u;
+                    publish_umax(thr_encode(ls[PUB - 1]), ((unsigned)tn * 16u + (ln & 15u)) * 32u + 4u * cls, thr_rsrc);
+                }
+            }
+        }
+        if (i + AHEAD + 1 < nb) pbase += blk_bytes;
+        stage = stage == STAGES - 1 ? 0 : stage + 1;
+        pstage = pstage == STAGES - 1 ? 0 : pstage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no DMA may outlive the workgroup's LDS allocation
+
+    // lists: [q][nsplit][8 = 2 document halves x 4 lane groups][KL]
+    if (reducer) {
+        const unsigned ln = lane_id_here();
+        const int q = qt * TN + tn * 16 + (int)(ln & 15u);
+        const size_t o = (((size_t)q * p.nsplit + split) * 8 + th * 4 + (int)(ln >> 4)) * KL;
+#pragma unroll
+        for (int i = 0; i < KL; ++i) {
+            p.part_s[o + i] = ls[i];
+            p.part_i[o + i] = li[i];
+        }
+    }
+}
+
+} // namespace mips

@@ -71,6 +71,10 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
     if (qt >= p.nqt) return;
     if (p.spin_limit < 0 && tid == 0) *p.err = 1u; // test-only: force the scan-error path (include/mips_hip.h, "spin_limit")
     const bool idle_wave = (qt * TN + wave * 32) >= p.nq;
+    // experiments (profiles/r3_v4_prio; results unchanged): TIMING_MODE 3 / 5 = static priority for the younger half of the
+    // workgroup (waves 4 .. 7 lose every issue arbitration against their SIMD partners 0 .. 3: MI355X_MICROARCH.md, "Two waves per
+    // SIMD", item 4); 4 / 5 = the arrival poll spins on s_nop instead of s_sleep 1 (64-cycle wake-up granularity)
+    if ((TIMING_MODE == 3 || TIMING_MODE == 5) && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     const int b0 = split * p.tiles_per_split;
     int b1 = b0 + p.tiles_per_split;
@@ -169,7 +173,13 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
                 if (lane == 0) *p.err = 1u;
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            if (TIMING_MODE == 4 || TIMING_MODE == 5) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("s_nop 15" ::: "memory");
+#endif
+            } else {
+                __builtin_amdgcn_s_sleep(1);
+            }
         }
     };
 
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (half == 1) arrive(); // all LDS reads of this block are done; the epilogue runs un-synchronised
-            if (half == 1 && refresh && TIMING_MODE == 0) {
+            if (half == 1 && refresh && TIMING_MODE != 1) {
                 // minimum of the 8 class words of queries c and 16 + c (what an earlier block's DMA brought, or 0);
                 // inline asm, one query at a time: see scan_kernel_v3.hpp
                 const unsigned thr_addr = thr_addr_of(lane_id_here());

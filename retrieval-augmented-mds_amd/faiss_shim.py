@@ -203,7 +203,7 @@ def read_index(reader) -> IndexFlat:
     if head.get("phi_seen") is not None:
         index._phi_seen = head["phi_seen"]
     inner = index._index()
-    npdt = {"bf16": np.uint16, "fp8_e4m3": np.uint8, "f32": np.float32}[head["dtype"]]
+    npdt = {"bf16": np.uint16, "fp8_e4m3": np.uint8, "fp8_e4m3_docs": np.uint8, "f32": np.float32}[head["dtype"]]
     row_bytes = head["inner_d"] * np.dtype(npdt).itemsize
     inner.reserve(head["ntotal"])
     for r0 in range(0, head["ntotal"], 1 << 16):

@@ -31,12 +31,15 @@ def _stream_handle(device: int) -> int:
 
 class MipsIndex:
     def __init__(self, d: int, metric: int = _lib.METRIC_IP, dtype: str = "bf16", device: int | None = None):
-        if dtype not in ("bf16", "fp8_e4m3", "f32"):
-            raise NotImplementedError(f"index dtype {dtype!r}: this build stores 'bf16', 'fp8_e4m3' or 'f32'")
+        if dtype not in ("bf16", "fp8_e4m3", "fp8_e4m3_docs", "f32"):
+            raise NotImplementedError(f"index dtype {dtype!r}: this build stores 'bf16', 'fp8_e4m3' (queries e4m3 too), "
+                                      "'fp8_e4m3_docs' (e4m3 rows, bf16 queries) or 'f32'")
         self._lib = _lib.load()
         self.device = _lib.require_gpu(device)
         self._h = ctypes.c_void_p()
-        self._code = {"bf16": _lib.DTYPE_BF16, "fp8_e4m3": _lib.DTYPE_FP8_E4M3, "f32": _lib.DTYPE_F32}[dtype]
+        self._code = {"bf16": _lib.DTYPE_BF16, "fp8_e4m3": _lib.DTYPE_FP8_E4M3, "fp8_e4m3_docs": _lib.DTYPE_FP8_E4M3_DOCS,
+                      "f32": _lib.DTYPE_F32}[dtype]
+        self._f8 = self._code in (_lib.DTYPE_FP8_E4M3, _lib.DTYPE_FP8_E4M3_DOCS)   # e4m3 storage
         _lib.check(self._lib.mips_index_create(ctypes.byref(self._h), self.device, int(d), self._code,
                                                int(metric)), "mips_index_create")
         self._d = int(d)
@@ -84,7 +87,7 @@ class MipsIndex:
                 code = _lib.DTYPE_F32
             elif x.dtype == torch.bfloat16:
                 code = _lib.DTYPE_BF16
-            elif x.dtype == getattr(torch, "float8_e4m3fn", None) and self._code == _lib.DTYPE_FP8_E4M3:
+            elif x.dtype == getattr(torch, "float8_e4m3fn", None) and self._f8 and not (what == "search" and self._code == _lib.DTYPE_FP8_E4M3_DOCS):
                 code = _lib.DTYPE_FP8_E4M3  # raw e4m3 bytes
             else:
                 x = x.float()
@@ -101,7 +104,7 @@ class MipsIndex:
         if a.dtype == np.uint16:  # raw bf16 bit patterns
             a = np.ascontiguousarray(a)
             return a.ctypes.data, _lib.DTYPE_BF16, 0, a.shape[0], a
-        if a.dtype == np.uint8 and self._code == _lib.DTYPE_FP8_E4M3:  # raw e4m3 codes
+        if a.dtype == np.uint8 and self._f8 and not (what == "search" and self._code == _lib.DTYPE_FP8_E4M3_DOCS):  # raw e4m3 codes
             a = np.ascontiguousarray(a)
             return a.ctypes.data, _lib.DTYPE_FP8_E4M3, 0, a.shape[0], a
         a = np.ascontiguousarray(a, dtype=np.float32)
@@ -144,7 +147,7 @@ class MipsIndex:
     def rows_raw(self, row0: int = 0, n: int | None = None) -> np.ndarray:
         """Stored rows in the index dtype: np.uint16 bf16 bits, np.uint8 e4m3 codes or np.float32, [n, d]."""
         n = self.ntotal - row0 if n is None else n
-        npdt = {_lib.DTYPE_BF16: np.uint16, _lib.DTYPE_FP8_E4M3: np.uint8, _lib.DTYPE_F32: np.float32}[self._code]
+        npdt = {_lib.DTYPE_BF16: np.uint16, _lib.DTYPE_FP8_E4M3: np.uint8, _lib.DTYPE_FP8_E4M3_DOCS: np.uint8, _lib.DTYPE_F32: np.float32}[self._code]
         out = np.empty((n, self._d), dtype=npdt)
         _lib.check(self._lib.mips_index_read_rows(self._h, int(row0), int(n), out.ctypes.data,
                                                   _stream_handle(self.device)), "mips_index_read_rows")
@@ -309,7 +312,7 @@ class MipsIndex:
         """Replaces Dataset.save_faiss_index (sotasum/mips.py:536)."""
         os.makedirs(path, exist_ok=True)
         n = self.ntotal
-        with open(os.path.join(path, "rows." + {"bf16": "bf16", "fp8_e4m3": "e4m3", "f32": "f32"}[self.dtype]), "wb") as f:
+        with open(os.path.join(path, "rows." + {"bf16": "bf16", "fp8_e4m3": "e4m3", "fp8_e4m3_docs": "e4m3", "f32": "f32"}[self.dtype]), "wb") as f:
             for r0 in range(0, n, chunk_rows):
                 f.write(self.rows_raw(r0, min(chunk_rows, n - r0)).tobytes())
         meta = {"format": _FORMAT_VERSION, "d": self._d, "ntotal": n, "metric": self._metric, "dtype": self.dtype}
@@ -335,7 +338,8 @@ class MipsIndex:
         n, d = meta["ntotal"], meta["d"]
         lo, hi = (0, n) if row_range is None else row_range
         if hi > lo:
-            ext, npdt = {"bf16": ("bf16", np.uint16), "fp8_e4m3": ("e4m3", np.uint8), "f32": ("f32", np.float32)}[meta["dtype"]]
+            ext, npdt = {"bf16": ("bf16", np.uint16), "fp8_e4m3": ("e4m3", np.uint8), "fp8_e4m3_docs": ("e4m3", np.uint8),
+                         "f32": ("f32", np.float32)}[meta["dtype"]]
             mm = np.memmap(os.path.join(path, "rows." + ext), dtype=npdt, mode="r", shape=(n, d))
             ix.reserve(hi - lo)
             for r0 in range(lo, hi, chunk_rows):

@@ -136,7 +136,7 @@ class ShardedMipsIndex:
 
         import torch.distributed as dist
 
-        ext = {"bf16": "bf16", "fp8_e4m3": "e4m3", "f32": "f32"}[self.local.dtype]
+        ext = {"bf16": "bf16", "fp8_e4m3": "e4m3", "fp8_e4m3_docs": "e4m3", "f32": "f32"}[self.local.dtype]
         if self.rank == 0:
             os.makedirs(path, exist_ok=True)
             open(os.path.join(path, "rows." + ext), "wb").close()

@@ -33,7 +33,7 @@ def _stored(index):
 def _as_stored(index, q):
     """what the index makes of float32 queries before it multiplies: rounded to its storage type, or left alone (fp32-exact)"""
     q = np.ascontiguousarray(q, dtype=np.float32)
-    if index.dtype == "bf16":
+    if index.dtype in ("bf16", "fp8_e4m3_docs"):                 # (e4m3 rows, bf16 queries)
         return synth.round_to_bf16(q)
     return q if index.dtype == "f32" else synth.round_to_e4m3(q)
 
@@ -1013,10 +1013,14 @@ def test_optimistic_pools_agree_with_true_lists_at_full_size():
     s1, i1 = ix.search(q, 10)
     assert ix.last_kernel.startswith("mips::scan_kernel_v4") and ix.last_kernel.endswith(", 4>")
     assert ix.margin_stats()["unresolved"] == 0
-    s2, i2 = ix.search(q, 14)
+    s2, i2 = ix.search(q, 14)                                     # (round 3: k = 14 .. 29 take the pools of 32 as well)
+    assert ix.last_kernel.startswith("mips::scan_kernel_v4") and ix.last_kernel.endswith(", 4>") and ix.margin_stats()["unresolved"] == 0
+    ix.set_param("optimistic", 0)
+    s3, i3 = ix.search(q, 14)
     assert ix.last_kernel.startswith("mips::scan_kernel_v3<32")
     assert torch.equal(i0, i1) and torch.equal(s0, s1)
     assert torch.equal(i0, i2[:, :10]) and torch.equal(s0, s2[:, :10])
+    assert torch.equal(i2, i3) and torch.equal(s2, s3)
 
 
 def test_f32_exact_two_stage_near_duplicates():
@@ -1772,31 +1776,40 @@ def test_fused_hook_search_prepare_search_ignore_in_one_call(tmp_path, metric, n
 
 
 def test_pitch_1024_k_split_kernel_is_bit_identical():
-    """scan_kernel_ks ("variant" = 6): a wave pair splits K at row pitch 1024, partial sums meet in LDS.  Same bits as
-    the default (scan_kernel_v3's one-wave-per-SIMD configuration) and as the oracle, ragged sizes, single- and
-    multi-tile query counts, ties."""
-    for n, nq, d, k in ((70001, 300, 1024, 5), (150001, 700, 1000, 5), (64 * 37 + 5, 129, 800, 4), (5000, 40, 1024, 1)):
+    """Row pitch 1024: scan_kernel_v3's one-wave-per-SIMD configuration ("variant" = 3; the default up to 256 queries),
+    scan_kernel_ks ("variant" = 6: a wave pair splits K, partial sums meet in LDS) and scan_kernel_k3 ("variant" = 7, the
+    default beyond 256 queries: the same pairs with 48 queries each, 192-query tiles, sub-lists of 4) return the same bits --
+    and the oracle's -- on ragged sizes, single- and multi-tile query counts, forced split counts, ties."""
+    for n, nq, d, k in ((70001, 300, 1024, 5), (150001, 700, 1000, 5), (64 * 37 + 5, 129, 800, 4), (5000, 40, 1024, 1), (40000, 193, 1024, 5)):
         ix = ram.MipsIndex(d)
         ix.add_synthetic(n, row0=0, seed=171, kind=synth.KIND_GAUSS)
         q = ram.synth_fill(nq, d, 0, 172, synth.KIND_GAUSS)
         ref_s, ref_i = ix.search(q, k)
-        assert "scan_kernel_v3" in ix.last_kernel
-        ix.set_param("variant", 6)
-        for ns in (0, 8, 40):
-            ix.set_param("nsplit", ns)
-            s, i = ix.search(q, k)
-            assert "scan_kernel_ks" in ix.last_kernel and torch.equal(i, ref_i) and torch.equal(s, ref_s), (n, nq, d, ns)
+        assert ("scan_kernel_k3" if nq > 256 else "scan_kernel_v3") in ix.last_kernel, ix.last_kernel
+        x = synth.generate(171, 0, n, d, synth.KIND_GAUSS)
+        es, ei = orc.search_exact(q.float().cpu().numpy(), x, k)
+        assert np.array_equal(ref_i.cpu().numpy(), ei) and np.array_equal(ref_s.cpu().numpy(), es)
+        for variant, name in ((6, "scan_kernel_ks"), (7, "scan_kernel_k3"), (3, "scan_kernel_v3")):
+            ix.set_param("variant", variant)
+            for ns in (0, 8, 40):
+                ix.set_param("nsplit", ns)
+                s, i = ix.search(q, k)
+                assert name in ix.last_kernel and torch.equal(i, ref_i) and torch.equal(s, ref_s), (n, nq, d, ns, variant)
+            ix.set_param("nsplit", 0)
+            hs, hi = ix.search(q.float().cpu().numpy(), k)        # host buffers: certified with a synchronisation
+            assert np.array_equal(hi, ei) and np.array_equal(hs, es) and ix.margin_stats()["unresolved"] == 0
         ix.check()
     x = synth.generate(5, 0, 3000, 1024, synth.KIND_LATTICE)
     ql = synth.generate(6, 0, 300, 1024, synth.KIND_LATTICE)
     x[10] = x[700]
     x[333] = x[700]
     ql[0] = x[700]
-    ix = _index(x)
-    ix.set_param("variant", 6)
-    s, i = ix.search(ql, 5)
     es, ei = orc.search_exact_bruteforce(ql, x, 5)
-    assert np.array_equal(i, ei) and np.array_equal(s, es) and "scan_kernel_ks" in ix.last_kernel
+    for variant, name in ((6, "scan_kernel_ks"), (7, "scan_kernel_k3"), (0, "scan_kernel_k3")):
+        ix = _index(x)
+        ix.set_param("variant", variant)
+        s, i = ix.search(ql, 5)
+        assert np.array_equal(i, ei) and np.array_equal(s, es) and name in ix.last_kernel
 
 
 def test_split_tail_searches_overlap_without_sharing_scratch():
@@ -2198,7 +2211,52 @@ def test_wide_k_pools_and_pitch_1024_lists(n, nq, d, k):
     f = ram.MipsIndex(d, dtype="f32")
     f.add(xf)
     s2, i2 = f.search(torch.from_numpy(qf).cuda(), k)
-    assert not f.last_kernel.startswith("mips::scan_kernel<"), f.last_kernel
+    # (k <= 13: two-stage search; beyond that the widened margin no longer fits between the k-th and the pool's 33rd score
+    # and the three-segment scan with true K' = 32 lists is the cheaper way to be exact)
+    assert f.last_kernel.startswith("mips::scan_kernel<32>") == (k > 13), f.last_kernel
     st = f.margin_stats()
     assert st["unresolved"] == 0 and st["flagged"] <= max(2, nq // 8), st
     assert np.array_equal(i2.cpu().numpy(), fi) and np.array_equal(s2.cpu().numpy(), fs)
+
+
+# ------------------------------------------------------------------ round 3: BASELINE config 5 as worded -- e4m3 documents, bf16 queries
+@pytest.mark.parametrize("n,nq,d,k,metric", [(5000, 8, 768, 5, 0), (70001, 64, 768, 5, 0), (30000, 40, 1024, 5, 0), (20000, 300, 768, 5, 0),
+                                               (9000, 33, 512, 6, 1), (3000, 7, 256, 1, 0), (25000, 16, 1000, 10, 0), (40000, 20, 640, 20, 0),
+                                               (64 * 31 + 3, 65, 768, 5, 1), (33, 3, 100, 5, 0)])
+def test_e4m3_documents_bf16_queries_parity(tmp_path, n, nq, d, k, metric):
+    """dtype "fp8_e4m3_docs": rows stored as OCP e4m3 (half the bytes of a bf16 index), queries kept in bf16, products on the bf16
+    MFMA after an exact e4m3 -> bf16 up-conversion (scan_kernel_e8: the 8 waves split K, partial sums meet in LDS).  Canonical
+    score = exact products of (e4m3 row element, bf16 query element), sequential fp64 sum: bit-identical to the oracle on those
+    operands -- host and device call shapes, single- and multi-tile query counts, ragged sizes, pools of 8 / 10 / 16 / 32, L2."""
+    rng = np.random.default_rng(n + nq)
+    x = (synth.generate(601, 0, n, d, synth.KIND_GAUSS) * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
+    q = (synth.generate(602, 0, nq, d, synth.KIND_GAUSS) * rng.uniform(0.5, 2.0, (nq, 1))).astype(np.float32)
+    x8, qb = synth.round_to_e4m3(x), synth.round_to_bf16(q)
+    es, ei = orc.search_exact(qb, x8, k, metric=metric)
+    ix = ram.MipsIndex(d, metric=metric, dtype="fp8_e4m3_docs")
+    ix.add(x[:n // 2])
+    ix.add(torch.from_numpy(x[n // 2:]).cuda())
+    assert np.array_equal(synth.e4m3_bits_to_f32(ix.rows_raw()), x8)
+    s, i = ix.search(q, k)
+    assert ix.last_kernel.startswith("mips::scan_kernel_e8"), ix.last_kernel
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+    st = ix.margin_stats()
+    assert st["unresolved"] == 0 and st["rescanned"] == st["flagged"], st
+    ds, di = ix.search(torch.from_numpy(q).cuda(), k)
+    assert np.array_equal(di.cpu().numpy(), ei) and np.array_equal(ds.cpu().numpy(), es) and ix.margin_stats()["unresolved"] == 0
+    ds, di = ix.search(torch.from_numpy(qb).cuda().bfloat16(), k, 1000)       # bf16 queries as they come, row offset
+    assert np.array_equal(di.cpu().numpy(), ei + 1000) and np.array_equal(ds.cpu().numpy(), es)
+    for ns in (8, 24):                                                        # forced split counts
+        ix.set_param("nsplit", ns)
+        s2, i2 = ix.search(q, k)
+        assert np.array_equal(i2, ei) and np.array_equal(s2, es), ns
+    ix.set_param("nsplit", 0)
+    ix.save(str(tmp_path / "ix"))
+    back = ram.MipsIndex.load(str(tmp_path / "ix"))
+    assert back.dtype == "fp8_e4m3_docs" and np.array_equal(back.rows_raw(), ix.rows_raw())
+    s3, i3 = back.search(q, k)
+    assert np.array_equal(i3, ei) and np.array_equal(s3, es)
+    # the all-e4m3 index of the same rows answers with e4m3-rounded queries: a different (coarser) question
+    both = ram.MipsIndex(d, metric=metric, dtype="fp8_e4m3")
+    both.add(x)
+    assert np.array_equal(both.rows_raw(), ix.rows_raw())
