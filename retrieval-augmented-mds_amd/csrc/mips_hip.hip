@@ -438,6 +438,62 @@ void swap_scratch_sets(mips_index* ix) {
     ix->cur_set ^= 1;
 }
 
+// ---- The shipped instances of the query-stationary bf16 scans, ONE ROW EACH: what selects an instance (row pitch, document cache
+// policy, published rank), what it needs (waves -> threads, ring stages -> LDS bytes), its entry point and the name rocprofv3
+// prints.  launch_search looks the row up; a new pitch / list length / policy is one more row here.
+struct ScanInstance {
+    int ld;            // row pitch in elements
+    bool nt;           // non-temporal document DMA (searches of one query tile: every block has a single reader)
+    int pub;           // scan_kernel_v4: rank every sub-list publishes (1: pools of 8, 4: pools of 32); 0 for scan_kernel_v3
+    int waves, stages; // per workgroup / of the LDS ring
+    const void* fn;    // __global__ entry taking ScanArgs by value
+    const char* name;  // printf format; scan_kernel_v3 rows take K' as their one %d
+};
+inline int scan_instance_lds(const ScanInstance& e) { // ring + class-word copies (1 KiB per wave) + dump area + arrival counter
+    return e.stages * mips::V3_DB * e.ld * 2 + e.waves * 1024 + 1024 + 16;
+}
+inline const ScanInstance* find_instance(const ScanInstance* t, int n, int ld, bool nt, int pub) {
+    for (int i = 0; i < n; ++i)
+        if (t[i].ld == ld && t[i].nt == nt && t[i].pub == pub) return &t[i];
+    return nullptr;
+}
+// scan_kernel_v4: 16x16x32 MFMA, 8 waves x 32 queries, 3-stage ring, 4 sub-lists of 6 per (query, split)
+#define MIPS_V4_ROW(KS, NT, PUB)                                                                                   \
+    {KS * 32, NT, PUB, 8, 3, (const void*)mips::scan_kernel_v4<6, KS, 2, 0, NT, PUB>, "mips::scan_kernel_v4<6, " #KS ", 2, 0, " #NT ", " #PUB ">"}
+#define MIPS_V4_PITCH(KS) MIPS_V4_ROW(KS, false, 1), MIPS_V4_ROW(KS, true, 1), MIPS_V4_ROW(KS, false, 4), MIPS_V4_ROW(KS, true, 4)
+inline const ScanInstance* v4_instances(int* n) {
+    static const ScanInstance t[] = {MIPS_V4_PITCH(12), MIPS_V4_PITCH(16), MIPS_V4_PITCH(20), MIPS_V4_PITCH(24)};
+    *n = (int)(sizeof t / sizeof t[0]);
+    return t;
+}
+// scan_kernel_v3: 32x32x16 MFMA, true K'-entry lists.  K' <= 10 at pitch <= 768: 8 waves (two per SIMD), 3-stage ring; K' = 16 /
+// 32 there: 4 waves (one per SIMD, 512 registers), 3-stage ring; pitch 1024 (256 fragment registers): 4 waves, 2 stages of 64 KiB
+#define MIPS_V3_ROW8(KS16, NT)                                                                                     \
+    {KS16 * 16, NT, 0, 8, 3, (const void*)mips::scan_kernel_v3<KL, KS16, 1, 2, true, 0, 2, 8, 3, true, NT>,        \
+     "mips::scan_kernel_v3<%d, " #KS16 ", 1, 2, true, 0, 2, 8, 3, true, " #NT ", 8>"}
+#define MIPS_V3_ROW4(KS16, NT)                                                                                     \
+    {KS16 * 16, NT, 0, 4, 3, (const void*)mips::scan_kernel_v3<KL, KS16, 1, 4, true, 0, 2, 4, 3, true, NT>,        \
+     "mips::scan_kernel_v3<%d, " #KS16 ", 1, 4, true, 0, 2, 4, 3, true, " #NT ", 8>"}
+#define MIPS_V3_ROW1024(NT)                                                                                        \
+    {1024, NT, 0, 4, 2, (const void*)mips::scan_kernel_v3<KL, 64, 1, 4, false, 0, 2, 4, 2, true, NT>,              \
+     "mips::scan_kernel_v3<%d, 64, 1, 4, false, 0, 2, 4, 2, true, " #NT ", 8>"}
+template <int KL>
+const ScanInstance* v3_instances(int* n) {
+    if constexpr (KL <= 10) {
+        static const ScanInstance t[] = {MIPS_V3_ROW8(8, false),  MIPS_V3_ROW8(8, true),  MIPS_V3_ROW8(16, false), MIPS_V3_ROW8(16, true),
+                                         MIPS_V3_ROW8(24, false), MIPS_V3_ROW8(24, true), MIPS_V3_ROW8(32, false), MIPS_V3_ROW8(32, true),
+                                         MIPS_V3_ROW8(40, false), MIPS_V3_ROW8(40, true), MIPS_V3_ROW8(48, false), MIPS_V3_ROW8(48, true),
+                                         MIPS_V3_ROW1024(false),  MIPS_V3_ROW1024(true)};
+        *n = (int)(sizeof t / sizeof t[0]);
+        return t;
+    } else {
+        static const ScanInstance t[] = {MIPS_V3_ROW4(16, false), MIPS_V3_ROW4(16, true), MIPS_V3_ROW4(32, false), MIPS_V3_ROW4(32, true),
+                                         MIPS_V3_ROW4(48, false), MIPS_V3_ROW4(48, true), MIPS_V3_ROW1024(false), MIPS_V3_ROW1024(true)};
+        *n = (int)(sizeof t / sizeof t[0]);
+        return t;
+    }
+}
+
 // scan_kernel_e8 (e4m3 documents x bf16 queries): instance by row pitch, query blocks per tile, ring depth, document cache policy
 template <int PUB>
 int launch_e8(mips_index* ix, const mips::ScanArgsE8& fa, int grid, int ncb, bool nt, hipStream_t st, int slot) {
@@ -519,9 +575,11 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // scan_kernel_k3 (round 3): the wave pairs of scan_kernel_ks with 48 queries each -- 192 stationary queries per CU, a third
     // less L2 -> LDS fill per flop, which is what bounds pitch 1024.  Default there once several 192-query tiles share the
     // document stream (the MFMA-bound regime); smaller searches keep the 128-query configuration ("variant" = 7 / 3 force one)
-    const bool want_k3 = ks_shape && ix->opt_sub == 0 && (ix->opt_variant == 7 || (ix->opt_variant == 0 && nq > 256));
+    const bool want_k3 = ks_shape && ix->opt_sub == 0 && (ix->opt_variant == 7 || ix->opt_variant == 8 || (ix->opt_variant == 0 && nq > 256));
     constexpr int K3_KLL = 4; // entries per sub-list (the third accumulator set is paid for with shorter lists)
-    const int tm = variant == 1 ? mips::TM : want_f8x ? mips::F8X_DB : mips::V3_DB; // documents per scheduling unit ("tile")
+    // scan_kernel_k3s: the same on 16-document stages (4-stage ring, three blocks in flight instead of one); "variant" = 8
+    const bool want_k3s = want_k3 && ix->opt_variant == 8;
+    const int tm = variant == 1 ? mips::TM : want_f8x ? mips::F8X_DB : want_k3s ? 16 : mips::V3_DB; // documents per scheduling unit ("tile")
     const int tn = variant == 1 ? mips::TN : e8 ? 16 * e8_ncb : want_k3 ? 192 : v3_waves * 32; // queries per workgroup
     const int wg_target = variant == 1 ? 512 : 256;                   // resident workgroups on 256 CUs
     const int64_t nq_pad = query_pad(ix, nq);
@@ -613,7 +671,26 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
 
     const int grid = qt_per_group * qgroups * nsplit;
     const int slot = ix->ev_next;
-    if (e8) {
+    // launch one row of the instance tables above
+    auto launch_row = [&](const ScanInstance* e, int name_arg) -> int {
+        if (e == nullptr) return fail(MIPS_E_UNSUPPORTED, "no scan-kernel instance for row pitch %d, K' = %d", ix->ld, KL);
+        const int lds = scan_instance_lds(*e);
+        HIP_TRY(hipFuncSetAttribute(e->fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if (ix->timing_armed) HIP_TRY(hipEventRecord(ix->ev0[slot], st));
+        void* kargs[] = {(void*)&a};
+        HIP_TRY(hipLaunchKernel(e->fn, dim3((unsigned)grid), dim3((unsigned)(e->waves * 64)), kargs, (size_t)lds, st));
+        set_kernel_name(ix, e->name, name_arg);
+        return MIPS_OK;
+    };
+    if (want_k3s) {
+        if constexpr (KL == 8) {
+            const int lds = 4 * 16 * ix->ld * 2 + 4 * 1536 + 8 * 3072 + 1024 + 64; // 4 stages of 16 documents + class-word copies + exchange slots + dump + counters
+            HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel_k3s<K3_KLL, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            if (ix->timing_armed) HIP_TRY(hipEventRecord(ix->ev0[slot], st));
+            mips::scan_kernel_k3s<K3_KLL, 32, 2><<<grid, 512, lds, st>>>(a);
+            set_kernel_name(ix, "mips::scan_kernel_k3s<%d, 32, 2, 0>", K3_KLL);
+        }
+    } else if (e8) {
         mips::ScanArgsE8 fa;
         fa.docs = ix->rows;
         fa.c = a;
@@ -661,6 +738,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         }
     } else if (want_v4) {
         if constexpr (KL == 8 || KL == 16 || KL == 32) {
+#ifdef MIPS_EXPERIMENTAL
             const int lds = 3 * mips::V3_DB * ix->ld * 2 + 8 * 1024 + 1024 + 16; // ring + threshold words + dump area + arrival counter
             auto go4 = [&](auto kern) -> int {
                 HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -668,7 +746,9 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
                 kern<<<grid, 512, lds, st>>>(a);
                 return MIPS_OK;
             };
+#endif
             int rc2;
+            bool named = false;
             const bool nt = nqt == 1 && ix->opt_sub != 30; // one query tile: every document block has a single reader
 #ifdef MIPS_EXPERIMENTAL
             if (ix->ld == 768 && ix->opt_sub == 8) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 1>); // timing only: no epilogue
@@ -677,19 +757,14 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             else if (ix->ld == 768 && ix->opt_sub == 45) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 5>); // both
             else
 #endif
-            if (v4_opt) { // pools of 16 / 32: every sub-list vouches for its 4th best (8 x 4 = 32 documents above the bound)
-                if (ix->ld == 768) rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 0, true, 4>) : go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 0, false, 4>);
-                else if (ix->ld == 640) rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 20, 2, 0, true, 4>) : go4(mips::scan_kernel_v4<V4_KLL, 20, 2, 0, false, 4>);
-                else if (ix->ld == 512) rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 16, 2, 0, true, 4>) : go4(mips::scan_kernel_v4<V4_KLL, 16, 2, 0, false, 4>);
-                else rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 12, 2, 0, true, 4>) : go4(mips::scan_kernel_v4<V4_KLL, 12, 2, 0, false, 4>);
-            } else
-            if (ix->ld == 768) rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 0, true>) : go4(mips::scan_kernel_v4<V4_KLL, 24, 2>);
-            else if (ix->ld == 640) rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 20, 2, 0, true>) : go4(mips::scan_kernel_v4<V4_KLL, 20, 2>);
-            else if (ix->ld == 512) rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 16, 2, 0, true>) : go4(mips::scan_kernel_v4<V4_KLL, 16, 2>);
-            else rc2 = nt ? go4(mips::scan_kernel_v4<V4_KLL, 12, 2, 0, true>) : go4(mips::scan_kernel_v4<V4_KLL, 12, 2>);
+            {   // pools of 8 (PUB 1) or, optimistic, of 16 / 32: every sub-list vouches for its 4th best (8 x 4 = 32 documents)
+                int nrow = 0;
+                const ScanInstance* rows = v4_instances(&nrow);
+                rc2 = launch_row(find_instance(rows, nrow, ix->ld, nt, v4_opt ? 4 : 1), 0);
+                named = rc2 == MIPS_OK;
+            }
             if (rc2) return rc2;
-            set_kernel_name(ix, nt ? "mips::scan_kernel_v4<%d, %d, 2, 0, true, %d>" : "mips::scan_kernel_v4<%d, %d, 2, 0, false, %d>", V4_KLL, ix->ld / 32,
-                            v4_opt ? 4 : 1);
+            if (!named) set_kernel_name(ix, "mips::scan_kernel_v4 experimental instance sub=%d", ix->opt_sub);
         }
     } else if (want_f8x) {
         if constexpr (KL == 8) {
@@ -755,6 +830,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         set_kernel_name(ix, "mips::scan_kernel<%d>", KL);
     } else if constexpr (!kl_short) {
         // 4-wave configuration, 3-stage ring (d <= 768: 3 x 48 KiB; pitch 1024: 2 x 64 KiB)
+#ifdef MIPS_EXPERIMENTAL
         const int lds = (ix->ld == 1024 ? 2 : 3) * mips::V3_DB * ix->ld * 2 + 4 * 1024 + 1024 + 16;
         auto go4 = [&](auto kern) -> int {
             HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -762,6 +838,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             kern<<<grid, 256, lds, st>>>(a);
             return MIPS_OK;
         };
+#endif
         int rc2;
 #ifdef MIPS_EXPERIMENTAL
         if (ix->ld == 768 && ix->opt_sub == 51) { // ring-depth experiment (profiles/r2_pitch1024): the same kernel on a 2-stage ring
@@ -770,24 +847,17 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             set_kernel_name(ix, "mips::scan_kernel_v3 experimental instance sub=51 (4 waves, 2 stages)");
         } else
 #endif
-        if (ix->ld == 1024) { // (round 3: true K' = 16 / 32 lists at pitch 1024 -- k = 8 .. 29 and stage 1 of the two-stage fp32
-            // search at Longformer-large width no longer fall back to the generic kernel)
-            rc2 = nqt == 1 ? go4(mips::scan_kernel_v3<KL, 64, 1, 4, false, 0, 2, 4, 2, true, true>) : go4(mips::scan_kernel_v3<KL, 64, 1, 4, false, 0, 2, 4, 2>);
-            if (rc2) return rc2;
-            set_kernel_name(ix, nqt == 1 ? "mips::scan_kernel_v3<%d, 64, 1, 4, false, 0, 2, 4, 2, true, true, 8>" : "mips::scan_kernel_v3<%d, 64, 1, 4, false, 0, 2, 4, 2, true, false, 8>", KL);
-        } else
-        if (nqt == 1) { // one query tile: non-temporal document DMA
-            if (ix->ld == 768) rc2 = go4(mips::scan_kernel_v3<KL, 48, 1, 4, true, 0, 2, 4, 3, true, true>);
-            else if (ix->ld == 512) rc2 = go4(mips::scan_kernel_v3<KL, 32, 1, 4, true, 0, 2, 4, 3, true, true>);
-            else rc2 = go4(mips::scan_kernel_v3<KL, 16, 1, 4, true, 0, 2, 4, 3, true, true>);
-        } else
-        if (ix->ld == 768) rc2 = go4(mips::scan_kernel_v3<KL, 48, 1, 4, true, 0, 2, 4, 3>);
-        else if (ix->ld == 512) rc2 = go4(mips::scan_kernel_v3<KL, 32, 1, 4, true, 0, 2, 4, 3>);
-        else rc2 = go4(mips::scan_kernel_v3<KL, 16, 1, 4, true, 0, 2, 4, 3>);
+        {   // true K' = 16 / 32 lists: pitches 256 / 512 / 768 and (round 3) 1024 -- k = 8 .. 29 and stage 1 of the two-stage fp32
+            // search at Longformer-large width no longer fall back to the generic kernel there
+            int nrow = 0;
+            const ScanInstance* rows = v3_instances<KL>(&nrow);
+            rc2 = launch_row(find_instance(rows, nrow, ix->ld, nqt == 1, 0), KL);
+        }
         if (rc2) return rc2;
-        if (ix->ld != 1024)
-            set_kernel_name(ix, nqt == 1 ? "mips::scan_kernel_v3<%d, %d, 1, 4, true, 0, 2, 4, 3, true, true, 8>" : "mips::scan_kernel_v3<%d, %d, 1, 4, true, 0, 2, 4, 3, true, false, 8>", KL, ix->ld / 16);
     } else {
+        int rc2 = MIPS_OK;
+        bool launched = false;
+#ifdef MIPS_EXPERIMENTAL
         const int lds = (v3_waves == 4 ? 2 : 3) * mips::V3_DB * ix->ld * 2 + v3_waves * 1024 + 1024 + 16; // ring + threshold words + dump area + arrival counter
         auto go = [&](auto kern, int threads) -> int {
             HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -795,10 +865,6 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             kern<<<grid, threads, lds, st>>>(a);
             return MIPS_OK;
         };
-        int rc2 = MIPS_OK;
-        bool launched = false;
-        set_kernel_name(ix, "mips::scan_kernel_v3<%d, %d, 1, 2, true, 0, 2, 8, 3, true, false, 8>", KL, ix->ld / 16);
-#ifdef MIPS_EXPERIMENTAL
         // A/B instances of the experiment logs under profiles/ (tools/ab.py builds the library with
         // -DMIPS_EXPERIMENTAL; the shipped library does not contain them: sub 8 / 9 return wrong results by design)
         const int sub = (KL == 8 && ix->ld == 768) ? ix->opt_sub : 0;
@@ -818,31 +884,11 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         else launched = false;
         if (launched) set_kernel_name(ix, "mips::scan_kernel_v3 experimental instance sub=%d", sub);
 #endif
-        if (launched) {
-        } else if (ix->ld == 1024 && nqt == 1) { // one query tile: non-temporal document DMA (as at pitch 768 below)
-            rc2 = go(mips::scan_kernel_v3<KL, 64, 1, 4, false, 0, 2, 4, 2, true, true>, 256);
-            set_kernel_name(ix, "mips::scan_kernel_v3<%d, 64, 1, 4, false, 0, 2, 4, 2, true, true, 8>", KL);
-        } else if (ix->ld == 1024) {
-            rc2 = go(mips::scan_kernel_v3<KL, 64, 1, 4, false, 0, 2, 4, 2>, 256);
-            set_kernel_name(ix, "mips::scan_kernel_v3<%d, 64, 1, 4, false, 0, 2, 4, 2, true, false, 8>", KL);
-        } else if (ix->ld == 768 && nqt == 1) {
-            // one query tile: every document block has a single reader, so its DMA is non-temporal (HBM-bound
-            // regime: 5.5 -> 5.9 TB/s)
-            rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true, 0, 2, 8, 3, true, true>, 512);
-            set_kernel_name(ix, "mips::scan_kernel_v3<%d, 48, 1, 2, true, 0, 2, 8, 3, true, true, 8>", KL);
-        } else if (ix->ld == 768) rc2 = go(mips::scan_kernel_v3<KL, 48, 1, 2, true>, 512);
-        else if (nqt == 1) { // one query tile at the other pitches: non-temporal document DMA as well
-            if (ix->ld == 640) rc2 = go(mips::scan_kernel_v3<KL, 40, 1, 2, true, 0, 2, 8, 3, true, true>, 512);
-            else if (ix->ld == 512) rc2 = go(mips::scan_kernel_v3<KL, 32, 1, 2, true, 0, 2, 8, 3, true, true>, 512);
-            else if (ix->ld == 384) rc2 = go(mips::scan_kernel_v3<KL, 24, 1, 2, true, 0, 2, 8, 3, true, true>, 512);
-            else if (ix->ld == 256) rc2 = go(mips::scan_kernel_v3<KL, 16, 1, 2, true, 0, 2, 8, 3, true, true>, 512);
-            else rc2 = go(mips::scan_kernel_v3<KL, 8, 1, 2, true, 0, 2, 8, 3, true, true>, 512);
-            set_kernel_name(ix, "mips::scan_kernel_v3<%d, %d, 1, 2, true, 0, 2, 8, 3, true, true, 8>", KL, ix->ld / 16);
-        } else if (ix->ld == 640) rc2 = go(mips::scan_kernel_v3<KL, 40, 1, 2, true>, 512);
-        else if (ix->ld == 512) rc2 = go(mips::scan_kernel_v3<KL, 32, 1, 2, true>, 512);
-        else if (ix->ld == 384) rc2 = go(mips::scan_kernel_v3<KL, 24, 1, 2, true>, 512);
-        else if (ix->ld == 256) rc2 = go(mips::scan_kernel_v3<KL, 16, 1, 2, true>, 512);
-        else rc2 = go(mips::scan_kernel_v3<KL, 8, 1, 2, true>, 512);
+        if (!launched) { // K' = 8 / 10: one query tile -> non-temporal document DMA (HBM-bound regime: 5.5 -> 5.9 TB/s at pitch 768)
+            int nrow = 0;
+            const ScanInstance* rows = v3_instances<KL>(&nrow);
+            rc2 = launch_row(find_instance(rows, nrow, ix->ld, nqt == 1, 0), KL);
+        }
         if (rc2) return rc2;
     }
     HIP_TRY(hipGetLastError());

@@ -44,7 +44,7 @@ for kind in ("gauss", "clustered"):
         ref.check()
         ti = ti.cpu().numpy()
         del ref
-        for dtype in ("bf16", "fp8_e4m3"):
+        for dtype in ("bf16", "fp8_e4m3", "fp8_e4m3_docs"):    # (the last: e4m3 rows, bf16 queries)
             ix = ram.MipsIndex(a.dim, dtype=dtype)
             ix.add(x)
             _, gi = ix.search(q, a.k)
