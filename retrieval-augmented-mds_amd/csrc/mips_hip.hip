@@ -575,11 +575,12 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // scan_kernel_k3 (round 3): the wave pairs of scan_kernel_ks with 48 queries each -- 192 stationary queries per CU, a third
     // less L2 -> LDS fill per flop, which is what bounds pitch 1024.  Default there once several 192-query tiles share the
     // document stream (the MFMA-bound regime); smaller searches keep the 128-query configuration ("variant" = 7 / 3 force one)
-    const bool want_k3 = ks_shape && ix->opt_sub == 0 && (ix->opt_variant == 7 || ix->opt_variant == 8 || (ix->opt_variant == 0 && nq > 256));
+    const bool want_k3 = ks_shape && ix->opt_sub == 0 && (ix->opt_variant == 7 || (ix->opt_variant == 0 && nq > 256));
     constexpr int K3_KLL = 4; // entries per sub-list (the third accumulator set is paid for with shorter lists)
-    // scan_kernel_k3s: the same on 16-document stages (4-stage ring, three blocks in flight instead of one); "variant" = 8
-    const bool want_k3s = want_k3 && ix->opt_variant == 8;
-    const int tm = variant == 1 ? mips::TM : want_f8x ? mips::F8X_DB : want_k3s ? 16 : mips::V3_DB; // documents per scheduling unit ("tile")
+    // (a variant on 16-document stages -- 4-stage ring, three blocks in flight, one barrier per 16 documents -- was built and
+    // measured 18 % SLOWER, 34.8 vs 29.5 ms at 2^22 x 1024: profiles/r3_pitch1024/README.md; what parks the waves is the barrier
+    // itself, not the landing of the pieces)
+    const int tm = variant == 1 ? mips::TM : want_f8x ? mips::F8X_DB : mips::V3_DB; // documents per scheduling unit ("tile")
     const int tn = variant == 1 ? mips::TN : e8 ? 16 * e8_ncb : want_k3 ? 192 : v3_waves * 32; // queries per workgroup
     const int wg_target = variant == 1 ? 512 : 256;                   // resident workgroups on 256 CUs
     const int64_t nq_pad = query_pad(ix, nq);
@@ -682,15 +683,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         set_kernel_name(ix, e->name, name_arg);
         return MIPS_OK;
     };
-    if (want_k3s) {
-        if constexpr (KL == 8) {
-            const int lds = 4 * 16 * ix->ld * 2 + 4 * 1536 + 8 * 3072 + 1024 + 64; // 4 stages of 16 documents + class-word copies + exchange slots + dump + counters
-            HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel_k3s<K3_KLL, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            if (ix->timing_armed) HIP_TRY(hipEventRecord(ix->ev0[slot], st));
-            mips::scan_kernel_k3s<K3_KLL, 32, 2><<<grid, 512, lds, st>>>(a);
-            set_kernel_name(ix, "mips::scan_kernel_k3s<%d, 32, 2, 0>", K3_KLL);
-        }
-    } else if (e8) {
+    if (e8) {
         mips::ScanArgsE8 fa;
         fa.docs = ix->rows;
         fa.c = a;

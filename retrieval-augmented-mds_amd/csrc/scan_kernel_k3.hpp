@@ -318,298 +318,3 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
 }
 
 } // namespace mips
-
-namespace mips {
-
-// scan_kernel_k3s: scan_kernel_k3 on a DEEPER ring -- 16-document stages.
-//
-// Counters of scan_kernel_k3 at 2^22 x 1024, Q = 4096 (profiles/r3_pitch1024): the chip holds 2.09 GHz (it is not the power
-// limit of the pitch-768 kernels), the MFMA pipe is busy 54 % of the cycles, and the waves spend a third of theirs PARKED --
-// on the vmcnt(0) before the block barrier: with 64-KiB blocks the 160 KiB of LDS hold a 2-stage ring, so the pieces of block
-// i + 1 are issued during block i and must have landed by its end.  The same 128 KiB as FOUR stages of 16 documents (32 KiB)
-// keep three blocks = 96 KiB in flight per CU, and a wave waits only for pieces it issued two blocks (of 16 documents) earlier:
-//   * a "block" is now one 16-document MFMA row tile; the wave pair still splits K, and ownership alternates by block: the wave
-//     whose role equals the block's parity OWNS it (adds the partner's partial sums, runs the epilogue), the other one hands its
-//     partial sums over through its 3-KiB LDS slot -- over two consecutive blocks this is scan_kernel_k3's foreign / own half;
-//   * one split barrier per block (arrival counter in LDS): all-arrived(i) = everyone is done reading stage i % 4 and everyone's
-//     share of block i + 1 has landed; the pieces of block i + 4 go into that stage right after it;
-//   * every wave issues PPW + 1 operations per block (the role-0 waves bring the pair's class words in two halves on alternating
-//     blocks, everybody else a dummy into the dump area), so the counted vmcnt means the same everywhere.
-// Query tiles, fragments, sub-lists of KL = 4, class words, exchange and epilogue are scan_kernel_k3's.
-template <int KL, int KS32, int AD, int TIMING_MODE = 0>
-__global__ __launch_bounds__(512, 2) void scan_kernel_k3s(ScanArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int WAVES = 8;
-    constexpr int PAIRS = 4;
-    constexpr int NCB = 3;
-    constexpr int TN = PAIRS * 16 * NCB;            // 192 queries per workgroup
-    constexpr int SD = 16;                          // documents per stage (= per block)
-    constexpr int STAGES = 4;
-    constexpr int AHEAD = STAGES - 1;
-    constexpr int STAGE_BYTES = SD * KS32 * 64;     // 16 rows x (32 KS32) k x 2 B = 32 KiB at pitch 1024
-    constexpr int PIECES = STAGE_BYTES / 1024;      // 8 rows x 128 B each: piece pc = slab * 2 + rg
-    constexpr int PPW = PIECES / WAVES;
-    constexpr int KH = KS32 / 2;                    // k32-steps of one K half
-    constexpr int PER_BLOCK = PPW + 1;
-    static_assert(KS32 % 4 == 0 && PIECES % WAVES == 0 && PPW <= KH, "");
-    static_assert(KL <= 8, "8 class words vouch for 8 documents");
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pair = wave >> 1;
-    const int role = wave & 1;                      // K half, and parity of the blocks this wave owns
-    const int c = lane & 15;
-    const int g = lane >> 4;
-
-    const int xcd = blockIdx.x & 7;
-    const int j0 = blockIdx.x >> 3;
-    const int qt = (xcd % p.qgroups) + p.qgroups * (j0 % p.qt_per_group);
-    const int split = (xcd / p.qgroups) * p.splits_per_group + j0 / p.qt_per_group;
-    if (qt >= p.nqt) return;
-    if (p.spin_limit < 0 && tid == 0) *p.err = 1u; // test-only: force the scan-error path (include/mips_hip.h, "spin_limit")
-    const bool idle_pair = (qt * TN + pair * 16 * NCB) >= p.nq;
-
-    const int b0 = split * p.tiles_per_split;       // (tiles = 16-document blocks for this kernel)
-    int b1 = b0 + p.tiles_per_split;
-    if (b1 > p.ntiles) b1 = p.ntiles;
-    const int nb = b1 > b0 ? b1 - b0 : 0;
-
-    bf16x8 bq[NCB][KH];
-#pragma unroll
-    for (int n = 0; n < NCB; ++n) {
-        const uint16_t* qrow = p.qbuf + ((int64_t)qt * TN + pair * 16 * NCB + n * 16 + c) * p.ld + 32 * KH * role + 8 * g;
-#pragma unroll
-        for (int j = 0; j < KH; ++j) bq[n][j] = *reinterpret_cast<const bf16x8*>(qrow + 32 * j);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-        for (int j = 0; j < KH; ++j) asm volatile("" : "+v"(bq[n][j]));
-#endif
-    }
-
-    float ls[NCB][KL];
-    int li[NCB][KL];
-    float thr[NCB];
-#pragma unroll
-    for (int n = 0; n < NCB; ++n) {
-        thr[n] = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < KL; ++i) {
-            ls[n][i] = -INFINITY;
-            li[n][i] = IDX_NONE;
-        }
-    }
-
-    // ---- LDS map: ring | one copy per pair of its class words (1.5 KiB) | exchange slots (3 KiB per wave) | dump (1 KiB) | counters
-    constexpr unsigned THR_PAIR = 16u * NCB * 32u;
-    constexpr unsigned THR_AREA = STAGES * STAGE_BYTES;
-    constexpr unsigned XCH_AREA = THR_AREA + PAIRS * THR_PAIR;
-    constexpr unsigned XCH_WAVE = NCB * 1024u;
-    constexpr unsigned DUMP_AREA = XCH_AREA + WAVES * XCH_WAVE;
-    constexpr unsigned CNT_AREA = DUMP_AREA + 1024u;
-    static_assert(CNT_AREA + 64 <= 160 * 1024, "LDS budget");
-    const __amdgpu_buffer_rsrc_t thr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(reinterpret_cast<unsigned char*>(p.gthr) + (int64_t)qt * (PAIRS * THR_PAIR)), 0, PAIRS * THR_PAIR, 0x00020000);
-    if (role == 0) {
-        *reinterpret_cast<uint4*>(smem + THR_AREA + pair * THR_PAIR + lane * 16u) = make_uint4(0u, 0u, 0u, 0u);
-        if (lane < 32) *reinterpret_cast<uint4*>(smem + THR_AREA + pair * THR_PAIR + 1024u + lane * 16u) = make_uint4(0u, 0u, 0u, 0u);
-    }
-    // ONE operation per wave and block.  part 0 / 1 = first KiB / last 512 B of the pair's class words (role 0, when `real`);
-    // everything else points out of range: no memory access, zeros into the dump area
-    auto thr_op = [&](bool real, int part) {
-        const unsigned ln = lane_id_here();
-        const bool mine = real && role == 0;
-        const unsigned at = (unsigned)part * 1024u + ln * 16u;
-        lds_void* dst = (lds_void*)(smem + (mine ? THR_AREA + pair * THR_PAIR + (unsigned)part * 1024u : DUMP_AREA));
-        const unsigned voff = (mine && at < THR_PAIR) ? (unsigned)pair * THR_PAIR + at : (0x40000000u | (ln * 16u));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(thr_rsrc, dst, 16, voff, 0, 0, 16);
-    };
-
-    // ---- LDS-DMA map: piece pc = slab * 2 + rg = rows 8 rg .. 8 rg + 7 of 64-k slab `slab` (2 KiB per slab)
-    const unsigned char* docs_b = reinterpret_cast<const unsigned char*>(p.docs);
-    const int64_t row_bytes = (int64_t)p.ld * 2;
-    auto issue_piece = [&](const unsigned char* blk_base, int stage, int i) {
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)blk_base, 0, (int)(SD * row_bytes), 0x00020000);
-        const int pc = wave + WAVES * i;
-        const int slab = pc >> 1, rg = pc & 1;
-        const unsigned ln = lane_id_here();
-        const unsigned lane_off0 = (ln >> 3) * (unsigned)(p.ld * 2) + (((ln & 7u) ^ ((ln >> 4) & 7u)) << 4);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + stage * STAGE_BYTES + pc * 1024), 16,
-                                                 rg ? (lane_off0 ^ 64u) : lane_off0, rg * 8 * (int)row_bytes + slab * 128, 0, 0);
-    };
-    auto rd0_of = [&](unsigned ln) {
-        const unsigned cc = ln & 15u, gg = ln >> 4;
-        return (int)(cc * 128u + ((gg ^ ((cc >> 1) & 7u)) << 4));
-    };
-
-    // ---- counters in LDS: [0] block barrier, [4 + wave] slots this wave has written
-    const unsigned cnt_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds_void*)(smem + CNT_AREA));
-    const unsigned xcnt_mine = cnt_lds + 16u + 4u * (unsigned)wave;
-    const unsigned xcnt_partner = cnt_lds + 16u + 4u * (unsigned)(wave ^ 1);
-    auto bump = [&](unsigned saddr) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        unsigned ta, tb;
-        if (lane_id_here() == 0u)
-            asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, 1\n\tds_add_u32 %0, %1" : "=&v"(ta), "=&v"(tb) : "s"(saddr) : "memory");
-#endif
-    };
-    auto poll = [&](unsigned addr, unsigned need) {
-        for (int spin = 0;; ++spin) {
-            unsigned v = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("v_mov_b32 %0, %1\n\tds_read_b32 %0, %0\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "s"(addr) : "memory");
-#endif
-            if (__builtin_amdgcn_readfirstlane(v) >= need) break;
-            if (spin > p.spin_limit) {
-                if (lane == 0) *p.err = 1u;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    };
-    auto arrive = [&]() { // this wave's share of the NEXT block has landed: everything but the youngest two blocks' operations
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PER_BLOCK) : "memory");
-        bump(cnt_lds);
-    };
-
-    auto epilogue = [&](f32x4 (&acc)[NCB], int blk) {
-        if (TIMING_MODE == 1) {
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]));
-#endif
-            return;
-        }
-        const float mx0 = fmaxf(fmaxf(acc[0][0], acc[0][1]), fmaxf(acc[0][2], acc[0][3]));
-        const float mx1 = fmaxf(fmaxf(acc[1][0], acc[1][1]), fmaxf(acc[1][2], acc[1][3]));
-        const float mx2 = fmaxf(fmaxf(acc[2][0], acc[2][1]), fmaxf(acc[2][2], acc[2][3]));
-        if (__ballot(mx0 > thr[0] || mx1 > thr[1] || mx2 > thr[2]) != 0ull) {
-            const unsigned ln = lane_id_here();
-            const int base = blk * SD + 4 * (int)(ln >> 4);
-#pragma unroll
-            for (int n = 0; n < NCB; ++n) {
-                const float mark = ls[n][0];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float s = acc[n][r];
-                    if (s > thr[n]) {
-                        list_insert<KL>(ls[n], li[n], s, base + r);
-                        thr[n] = fmaxf(thr[n], ls[n][KL - 1]);
-                    }
-                }
-                if (ls[n][0] > mark) {
-                    const unsigned cls = (4u * (unsigned)split + (ln >> 4)) & 7u;
-                    publish_umax(thr_encode(ls[n][0]), (unsigned)pair * THR_PAIR + (16u * n + (ln & 15u)) * 32u + 4u * cls, thr_rsrc);
-                }
-            }
-        }
-    };
-
-    const unsigned char* first = docs_b + (int64_t)b0 * SD * row_bytes;
-    const unsigned char* last = docs_b + (int64_t)(b1 - 1) * SD * row_bytes;
-    const int64_t blk_bytes = SD * row_bytes;
-    if (tid < 16) reinterpret_cast<unsigned*>(smem + CNT_AREA)[tid] = 0u;
-    if (nb > 0) {
-#pragma unroll
-        for (int a = 0; a < AHEAD; ++a) { // same operation sequence as steady-state blocks (vmcnt arithmetic)
-            thr_op(true, a & 1);
-#pragma unroll
-            for (int i = 0; i < PPW; ++i) issue_piece(a < nb ? first + a * blk_bytes : last, a, i);
-        }
-    }
-    __syncthreads();
-    const unsigned char* pbase = nb > AHEAD ? first + AHEAD * blk_bytes : last;
-    int stage = 0, pstage = AHEAD;
-    unsigned arrivals_needed = 0, own_seen = 0;
-    if (nb > 0) arrive(); // this wave's share of block 0 has landed
-    for (int i = 0; i < nb; ++i) {
-        const int blk = b0 + i;
-        const bool refresh = i < 16 || ((i >> 1) & 7) == 0; // both halves of the class words, on two consecutive blocks
-        const bool own = (blk & 1) == role;
-        arrivals_needed += WAVES;
-        poll(cnt_lds, arrivals_needed); // every share of block i landed; everyone is done with block i - 1 (stage pstage)
-        thr_op(refresh, i & 1);
-        if (idle_pair) {
-#pragma unroll
-            for (int t = 0; t < PPW; ++t) issue_piece(pbase, pstage, t);
-            arrive();
-        } else {
-            const unsigned char* sa = smem + stage * STAGE_BYTES + (KH / 2) * role * 2048;
-            const int rd0 = rd0_of(lane_id_here());
-            auto lds_frag = [&](int j) { return *reinterpret_cast<const bf16x8*>(sa + (j >> 1) * 2048 + ((j & 1) ? (rd0 ^ 64) : rd0)); };
-            bf16x8 ar[AD];
-#pragma unroll
-            for (int t = 0; t < AD; ++t) ar[t] = lds_frag(t);
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 acc[NCB];
-#pragma unroll
-            for (int n = 0; n < NCB; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < KH; ++j) {
-#pragma unroll
-                for (int n = 0; n < NCB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[j % AD], bq[n][j], acc[n], 0, 0, 0);
-                if (j + AD < KH) ar[j % AD] = lds_frag(j + AD);
-                if (j < PPW) issue_piece(pbase, pstage, j); // block i + 3 into the stage block i - 1 left
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (!own) { // hand the partial sums to the partner (a wave's LDS operations complete in order: slot, then counter)
-                unsigned char* slot = smem + XCH_AREA + wave * XCH_WAVE + lane_id_here() * 16u;
-#pragma unroll
-                for (int n = 0; n < NCB; ++n) *reinterpret_cast<f32x4*>(slot + 1024 * n) = acc[n];
-                bump(xcnt_mine);
-                arrive();
-            } else {
-                ++own_seen;
-                poll(xcnt_partner, own_seen);
-                {
-                    const unsigned char* slot = smem + XCH_AREA + (wave ^ 1) * XCH_WAVE + lane_id_here() * 16u;
-#pragma unroll
-                    for (int n = 0; n < NCB; ++n) acc[n] = acc[n] + *reinterpret_cast<const f32x4*>(slot + 1024 * n);
-                }
-                arrive(); // chain done, the partner's slot read, this wave's share of the next block landed
-                if (refresh && TIMING_MODE == 0) {
-                    const unsigned a0 = (unsigned)(size_t)(lds_void*)smem + THR_AREA + pair * THR_PAIR + (lane_id_here() & 15u) * 32u;
-#pragma unroll
-                    for (int n = 0; n < NCB; ++n) {
-                        u32x4 w0 = {0u, 0u, 0u, 0u}, w1 = w0;
-#if defined(__HIP_DEVICE_COMPILE__)
-                        if (n == 0) asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(w0), "=&v"(w1) : "v"(a0) : "memory");
-                        else if (n == 1) asm volatile("ds_read_b128 %0, %2 offset:512\n\tds_read_b128 %1, %2 offset:528\n\ts_waitcnt lgkmcnt(0)" : "=&v"(w0), "=&v"(w1) : "v"(a0) : "memory");
-                        else asm volatile("ds_read_b128 %0, %2 offset:1024\n\tds_read_b128 %1, %2 offset:1040\n\ts_waitcnt lgkmcnt(0)" : "=&v"(w0), "=&v"(w1) : "v"(a0) : "memory");
-#endif
-                        const unsigned key = min(min(min(w0[0], w0[1]), min(w0[2], w0[3])), min(min(w1[0], w1[1]), min(w1[2], w1[3])));
-                        thr[n] = fmaxf(thr[n], key > 1u ? thr_decode(key - 1u) : -INFINITY);
-                    }
-                }
-                if ((int64_t)(blk + 1) * SD > p.ntotal) { // ragged last block of the index (uniform)
-                    const int base = blk * SD + 4 * (int)(lane_id_here() >> 4);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if ((int64_t)(base + r) >= p.ntotal) {
-#pragma unroll
-                            for (int n = 0; n < NCB; ++n) acc[n][r] = -INFINITY;
-                        }
-                }
-                epilogue(acc, blk);
-            }
-        }
-        if (i + AHEAD + 1 < nb) pbase += blk_bytes;
-        stage = stage == STAGES - 1 ? 0 : stage + 1;
-        pstage = pstage == STAGES - 1 ? 0 : pstage + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    // lists: [q][nsplit][8 = 2 block parities x 4 lane groups][KL]
-#pragma unroll
-    for (int n = 0; n < NCB; ++n) {
-        const unsigned ln = lane_id_here();
-        const int q = qt * TN + pair * 16 * NCB + n * 16 + (int)(ln & 15u);
-        const size_t o = (((size_t)q * p.nsplit + split) * 8 + role * 4 + (int)(ln >> 4)) * KL;
-#pragma unroll
-        for (int i = 0; i < KL; ++i) {
-            p.part_s[o + i] = ls[n][i];
-            p.part_i[o + i] = li[n][i];
-        }
-    }
-}
-
-} // namespace mips

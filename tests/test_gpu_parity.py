@@ -1789,7 +1789,7 @@ def test_pitch_1024_k_split_kernel_is_bit_identical():
         x = synth.generate(171, 0, n, d, synth.KIND_GAUSS)
         es, ei = orc.search_exact(q.float().cpu().numpy(), x, k)
         assert np.array_equal(ref_i.cpu().numpy(), ei) and np.array_equal(ref_s.cpu().numpy(), es)
-        for variant, name in ((6, "scan_kernel_ks"), (7, "scan_kernel_k3<"), (8, "scan_kernel_k3s"), (3, "scan_kernel_v3")):
+        for variant, name in ((6, "scan_kernel_ks"), (7, "scan_kernel_k3<"), (3, "scan_kernel_v3")):
             ix.set_param("variant", variant)
             for ns in (0, 8, 40):
                 ix.set_param("nsplit", ns)
@@ -1805,7 +1805,7 @@ def test_pitch_1024_k_split_kernel_is_bit_identical():
     x[333] = x[700]
     ql[0] = x[700]
     es, ei = orc.search_exact_bruteforce(ql, x, 5)
-    for variant, name in ((6, "scan_kernel_ks"), (7, "scan_kernel_k3<"), (8, "scan_kernel_k3s"), (0, "scan_kernel_k3")):
+    for variant, name in ((6, "scan_kernel_ks"), (7, "scan_kernel_k3<"), (0, "scan_kernel_k3")):
         ix = _index(x)
         ix.set_param("variant", variant)
         s, i = ix.search(ql, 5)
