@@ -494,28 +494,37 @@ const ScanInstance* v3_instances(int* n) {
     }
 }
 
-// scan_kernel_e8 (e4m3 documents x bf16 queries): instance by row pitch, query blocks per tile, ring depth, document cache policy
+// scan_kernel_e8 (e4m3 documents x bf16 queries): instance by row pitch, query blocks per tile (1 / 2 / 4: tiles of 16 / 32 / 64
+// queries), ring depth, document cache policy.  Tiles of <= 32 queries run the pipelined one-barrier-per-block form where two
+// slot buffers fit next to the ring (everywhere but 32-query tiles at pitch 1024)
+inline bool e8_pipelined(int ld, int ncb) { return ncb == 1 || (ncb == 2 && ld <= 768); }
+inline int e8_stages(int ld, int ncb) { return ncb == 1 && ld <= 768 ? 4 : 3; }
 template <int PUB>
 int launch_e8(mips_index* ix, const mips::ScanArgsE8& fa, int grid, int ncb, bool nt, hipStream_t st, int slot) {
-    const int stages = ncb == 2 && ix->ld <= 768 ? 4 : 3;
-    const int lds = stages * mips::V3_DB * ix->ld + 8 * (2 * ncb) * 1024 + 2048 + 1024 + 64; // ring + exchange slots + class words + dump + counters
+    const int stages = e8_stages(ix->ld, ncb);
+    const bool pipe = e8_pipelined(ix->ld, ncb);
+    // ring + slot buffer(s) + class words + dump + counters
+    const int lds = stages * mips::V3_DB * ix->ld + (pipe ? 2 : 1) * 8 * (2 * ncb) * 1024 + 2048 + 1024 + 64;
     auto go = [&](auto kern) -> int {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         if (ix->timing_armed) HIP_TRY(hipEventRecord(ix->ev0[slot], st));
         kern<<<grid, 512, lds, st>>>(fa);
         return MIPS_OK;
     };
-#define MIPS_E8_PITCH(LDB)                                                                                            \
-    if (ix->ld == LDB) {                                                                                              \
-        if (ncb == 2) return nt ? go(mips::scan_kernel_e8<6, LDB, 2, (LDB <= 768 ? 4 : 3), true, PUB>)                \
-                                : go(mips::scan_kernel_e8<6, LDB, 2, (LDB <= 768 ? 4 : 3), false, PUB>);              \
-        if constexpr (LDB <= 768) return nt ? go(mips::scan_kernel_e8<6, LDB, 4, 3, true, PUB>) : go(mips::scan_kernel_e8<6, LDB, 4, 3, false, PUB>); \
+#define MIPS_E8_ROW(LDB, NCB, STG, PIPE) \
+    return nt ? go(mips::scan_kernel_e8<6, LDB, NCB, STG, true, PUB, PIPE>) : go(mips::scan_kernel_e8<6, LDB, NCB, STG, false, PUB, PIPE>)
+#define MIPS_E8_PITCH(LDB)                                              \
+    if (ix->ld == LDB) {                                                \
+        if (ncb == 1) { MIPS_E8_ROW(LDB, 1, (LDB <= 768 ? 4 : 3), true); } \
+        if (ncb == 2) { MIPS_E8_ROW(LDB, 2, 3, (LDB <= 768)); }         \
+        if constexpr (LDB <= 768) { MIPS_E8_ROW(LDB, 4, 3, false); }    \
     }
     MIPS_E8_PITCH(256)
     MIPS_E8_PITCH(512)
     MIPS_E8_PITCH(768)
     MIPS_E8_PITCH(1024)
 #undef MIPS_E8_PITCH
+#undef MIPS_E8_ROW
     return fail(MIPS_E_UNSUPPORTED, "e4m3-documents index: no scan instance for row pitch %d with %d query blocks", ix->ld, ncb);
 }
 
@@ -550,7 +559,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // row pitch 1024) or 64; pools of 8 / 10 / 16 / 32 out of 8 sub-lists of 6 per (query, split), the class words vouching for
     // 8 PUB documents
     const bool e8 = ix->mixed;
-    const int e8_ncb = (ix->ld == 1024 || nq <= 32) ? 2 : 4;
+    const int e8_ncb = nq <= 16 ? 1 : (ix->ld == 1024 || nq <= 32) ? 2 : 4;
     if (e8) {
         if (ix->ld % 256 != 0 || ix->ld > 1024) return fail(MIPS_E_UNSUPPORTED, "e4m3-documents index: d must pad to 256/512/768/1024");
         variant = 3;
@@ -575,7 +584,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // scan_kernel_k3 (round 3): the wave pairs of scan_kernel_ks with 48 queries each -- 192 stationary queries per CU, a third
     // less L2 -> LDS fill per flop, which is what bounds pitch 1024.  Default there once several 192-query tiles share the
     // document stream (the MFMA-bound regime); smaller searches keep the 128-query configuration ("variant" = 7 / 3 force one)
-    const bool want_k3 = ks_shape && ix->opt_sub == 0 && (ix->opt_variant == 7 || (ix->opt_variant == 0 && nq > 256));
+    const bool want_k3 = ks_shape && (ix->opt_sub == 0 || (ix->opt_sub >= 61 && ix->opt_sub <= 66)) && (ix->opt_variant == 7 || (ix->opt_variant == 0 && nq > 256));
     constexpr int K3_KLL = 4; // entries per sub-list (the third accumulator set is paid for with shorter lists)
     // (a variant on 16-document stages -- 4-stage ring, three blocks in flight, one barrier per 16 documents -- was built and
     // measured 18 % SLOWER, 34.8 vs 29.5 ms at 2^22 x 1024: profiles/r3_pitch1024/README.md; what parks the waves is the barrier
@@ -691,13 +700,30 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         const bool nt = nqt == 1;
         int rc2 = launch_e8<PUB>(ix, fa, grid, e8_ncb, nt, st, slot);
         if (rc2) return rc2;
-        set_kernel_name(ix, "mips::scan_kernel_e8<6, %d, %d, %d, %s, %d>", ix->ld, e8_ncb, e8_ncb == 2 && ix->ld <= 768 ? 4 : 3, nt ? "true" : "false", PUB);
+        set_kernel_name(ix, "mips::scan_kernel_e8<6, %d, %d, %d, %s, %d, %s>", ix->ld, e8_ncb, e8_stages(ix->ld, e8_ncb), nt ? "true" : "false", PUB,
+                        e8_pipelined(ix->ld, e8_ncb) ? "true" : "false");
     } else if (want_k3) {
         if constexpr (KL == 8) {
             const int lds = 2 * mips::V3_DB * ix->ld * 2 + 4 * 1536 + 8 * 3072 + 64; // ring + the pairs' class-word copies + exchange slots + counters
-            HIP_TRY(hipFuncSetAttribute((const void*)mips::scan_kernel_k3<K3_KLL, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            if (ix->timing_armed) HIP_TRY(hipEventRecord(ix->ev0[slot], st));
-            mips::scan_kernel_k3<K3_KLL, 32, 2><<<grid, 512, lds, st>>>(a);
+            auto gok3 = [&](auto kern) -> int {
+                HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                if (ix->timing_armed) HIP_TRY(hipEventRecord(ix->ev0[slot], st));
+                kern<<<grid, 512, lds, st>>>(a);
+                return MIPS_OK;
+            };
+            int rc3;
+#ifdef MIPS_EXPERIMENTAL
+            // diagnostic builds (wrong results by design; profiles/r3_pitch1024): no epilogue / no document DMA / no pair hand-shake
+            if (ix->opt_sub == 61) rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 1>);
+            else if (ix->opt_sub == 62) rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 2>);
+            else if (ix->opt_sub == 63) rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 3>);
+            else if (ix->opt_sub == 64) rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 4>); // other schedules of the DMA pieces (results unchanged)
+            else if (ix->opt_sub == 65) rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 5>);
+            else if (ix->opt_sub == 66) rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 6>);
+            else
+#endif
+            rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2>);
+            if (rc3) return rc3;
             set_kernel_name(ix, "mips::scan_kernel_k3<%d, 32, 2, 0>", K3_KLL);
         }
     } else if (want_ks) {

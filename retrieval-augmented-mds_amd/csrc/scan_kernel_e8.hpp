@@ -18,8 +18,11 @@
 //     block of the same documents would be 48 KiB -- the point of the exercise; LDS image, XOR swizzle and LDS-DMA pieces are
 //     scan_kernel_v4's with 128-BYTE slabs (128 k instead of 64); lane (c, g) reads the 8 bytes of row c, k = 32 s + 8 g with
 //     one ds_read_b64 (conflict-free: 16-byte chunk slot = chunk ^ ((row >> 1) & 7), the two 8-byte halves side by side);
-//   * two counter barriers per block in LDS (inline asm, bounded polls): A = everybody's share of the block has landed and
-//     everybody is done with the previous block's slots, B = everybody's partial sums are written.
+//   * counter barriers in LDS (inline asm, bounded polls).  PIPE (tiles of <= 32 queries, where two slot buffers fit): ONE barrier
+//     per block -- block i is multiplied into slot buffer i & 1 while the reducing waves sum block i - 1 out of the other buffer;
+//     all-arrived(i) = everybody's share of block i has landed, everybody's partial sums of block i - 1 are written, everybody is
+//     done reading buffer i & 1 (the sums of block i - 2).  Otherwise two per block: A = landed + done with the previous block's
+//     slots, B = partial sums written.
 // Shared insert bounds: 8 class words per query, class (4 split + g) & 7, as scan_kernel_v4; every sub-list publishes its PUB-th
 // best, so the words vouch for 8 PUB documents: PUB = 1 for pools of 8, 2 for pools of 10 / 16, 4 for pools of 32 (the margin
 // check decides per query whether a pool selected from sub-lists of 6 was wide enough, as for scan_kernel_v4's optimistic pools).
@@ -59,9 +62,9 @@ __device__ __forceinline__ bf16x8 e4m3x8_to_bf16x8(unsigned lo, unsigned hi) {
     return r;
 }
 
-// KL: entries per sub-list; LDB: row pitch in bytes = padded K (256 .. 1024); NCB: 16-query column blocks per tile (2 or 4);
-// STAGES: ring depth; NT_DOCS: non-temporal document DMA (one query tile: every block has a single reader)
-template <int KL, int LDB, int NCB, int STAGES, bool NT_DOCS, int PUB = 1>
+// KL: entries per sub-list; LDB: row pitch in bytes = padded K (256 .. 1024); NCB: 16-query column blocks per tile (1, 2 or 4);
+// STAGES: ring depth; NT_DOCS: non-temporal document DMA (one query tile: every block has a single reader); PIPE: see above
+template <int KL, int LDB, int NCB, int STAGES, bool NT_DOCS, int PUB = 1, bool PIPE = false>
 __global__ __launch_bounds__(512, 2) void scan_kernel_e8(ScanArgsE8 pa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ScanArgs& p = pa.c;
@@ -80,7 +83,8 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_e8(ScanArgsE8 pa) {
     // ---- LDS map: ring | exchange slots [wave][tile][64 lanes][4 floats] | class words of the tile's queries (+ dump) | counters
     constexpr unsigned XCH_AREA = STAGES * STAGE_BYTES;
     constexpr unsigned XCH_WAVE = TILES * 1024u;
-    constexpr unsigned THR_AREA = XCH_AREA + WAVES * XCH_WAVE;   // 16 NCB queries x 32 B (<= 2 KiB), refreshed by wave 0
+    constexpr unsigned XCH_BUF = WAVES * XCH_WAVE;               // one buffer of slots; PIPE keeps two
+    constexpr unsigned THR_AREA = XCH_AREA + (PIPE ? 2u : 1u) * XCH_BUF; // 16 NCB queries x 32 B (<= 2 KiB)
     constexpr unsigned THR_BYTES = TN * 32u;
     constexpr unsigned DUMP_AREA = THR_AREA + 2048u;             // 1 KiB: where the dummy refresh "lands"
     constexpr unsigned CNT_AREA = DUMP_AREA + 1024u;
@@ -195,100 +199,120 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_e8(ScanArgsE8 pa) {
     __syncthreads();
     const unsigned char* pbase = nb > AHEAD ? first + AHEAD * blk_bytes : last;
     int stage = 0, pstage = AHEAD;
-    for (int i = 0; i < nb; ++i) {
-        const int blk = b0 + i;
-        const bool refresh = i < 8 || (i & 7) == 0;
-        // barrier A: this wave's share of block i has landed (everything but the youngest AHEAD - 1 blocks' operations) ...
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PER_BLOCK) : "memory");
-        bump(cnt_a);
-        poll(cnt_a, (unsigned)(i + 1) * WAVES); // ... and everybody's; everybody is also done with block i - 1 (its stage, the slots)
-        // block i + AHEAD goes into the stage block i - 1 just left
-        refresh_thresholds(refresh);
-#pragma unroll
-        for (int t = 0; t < PPW; ++t) issue_piece(pbase, pstage, t);
 
-        // ---- this wave's K slice of the block: convert + multiply
-        const unsigned char* sa = smem + stage * STAGE_BYTES;
+    // this wave's K slice of the block in ring stage `stg`: convert + multiply, partial sums -> its slot of buffer `buf`
+    auto multiply = [&](int stg, unsigned buf) {
+        const unsigned char* sa = smem + stg * STAGE_BYTES;
         f32x4 acc[2][NCB];
 #pragma unroll
         for (int half = 0; half < 2; ++half)
 #pragma unroll
             for (int n = 0; n < NCB; ++n) acc[half][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        {
-            const unsigned ln = lane_id_here();
-            const unsigned cc = ln & 15u, gg = ln >> 4;
-            const unsigned rowoff = cc * 128u + 8u * (gg & 1u);
-            const unsigned swz = (cc >> 1) & 7u;
+        const unsigned ln = lane_id_here();
+        const unsigned cc = ln & 15u, gg = ln >> 4;
+        const unsigned rowoff = cc * 128u + 8u * (gg & 1u);
+        const unsigned swz = (cc >> 1) & 7u;
 #pragma unroll
-            for (int j = 0; j < KS; ++j) {
-                const int sg = KS * wave + j;              // global k32-step (wave-uniform)
-                const unsigned chunk = 2u * (unsigned)(sg & 3) + (gg >> 1);
-                const unsigned off = (unsigned)(sg >> 2) * 4096u + rowoff + ((chunk ^ swz) << 4);
-                // (inline asm: behind an ordinary load of an LDS-DMA destination hipcc first drains vmcnt(0) -- the whole ring)
-                uint2 raw[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+        for (int j = 0; j < KS; ++j) {
+            const int sg = KS * wave + j;              // global k32-step (wave-uniform)
+            const unsigned chunk = 2u * (unsigned)(sg & 3) + (gg >> 1);
+            const unsigned off = (unsigned)(sg >> 2) * 4096u + rowoff + ((chunk ^ swz) << 4);
+            // (inline asm: behind an ordinary load of an LDS-DMA destination hipcc first drains vmcnt(0) -- the whole ring)
+            uint2 raw[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
 #if defined(__HIP_DEVICE_COMPILE__)
-                {
-                    const unsigned a0 = (unsigned)(size_t)(lds_void*)sa + off;
-                    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:2048\n\ts_waitcnt lgkmcnt(0)" : "=&v"(raw[0]), "=&v"(raw[1]) : "v"(a0) : "memory");
-                }
+            {
+                const unsigned a0 = (unsigned)(size_t)(lds_void*)sa + off;
+                asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:2048\n\ts_waitcnt lgkmcnt(0)" : "=&v"(raw[0]), "=&v"(raw[1]) : "v"(a0) : "memory");
+            }
 #endif
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const bf16x8 af = e4m3x8_to_bf16x8(raw[half].x, raw[half].y);
+            for (int half = 0; half < 2; ++half) {
+                const bf16x8 af = e4m3x8_to_bf16x8(raw[half].x, raw[half].y);
 #pragma unroll
-                    for (int n = 0; n < NCB; ++n) acc[half][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bq[n][j], acc[half][n], 0, 0, 0);
-                }
+                for (int n = 0; n < NCB; ++n) acc[half][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bq[n][j], acc[half][n], 0, 0, 0);
             }
-            // ---- partial sums -> this wave's slot
-            unsigned char* slot = smem + XCH_AREA + wave * XCH_WAVE + ln * 16u;
-#pragma unroll
-            for (int half = 0; half < 2; ++half)
-#pragma unroll
-                for (int n = 0; n < NCB; ++n) *reinterpret_cast<f32x4*>(slot + (half * NCB + n) * 1024) = acc[half][n];
         }
-        bump(cnt_b); // (a wave's LDS operations complete in order: the counter is visible after the slot)
-        if (reducer) {
-            poll(cnt_b, (unsigned)(i + 1) * WAVES);
-            const unsigned ln = lane_id_here();
-            const unsigned char* src = smem + XCH_AREA + (unsigned)wave * 1024u + ln * 16u; // tile `wave` of every slot
-            f32x4 sum = *reinterpret_cast<const f32x4*>(src);
+        unsigned char* slot = smem + XCH_AREA + buf * XCH_BUF + wave * XCH_WAVE + ln * 16u;
 #pragma unroll
-            for (int w = 1; w < WAVES; ++w) sum = sum + *reinterpret_cast<const f32x4*>(src + w * XCH_WAVE); // slot order
-            if (refresh) { // minimum of the 8 class words of query 16 tn + c (what an earlier refresh brought, or 0)
-                const unsigned a0 = (unsigned)(size_t)(lds_void*)smem + THR_AREA + ((unsigned)tn * 16u + (ln & 15u)) * 32u;
-                u32x4 w0 = {0u, 0u, 0u, 0u}, w1 = w0;
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int n = 0; n < NCB; ++n) *reinterpret_cast<f32x4*>(slot + (half * NCB + n) * 1024) = acc[half][n];
+    };
+    // (reducing waves) tile `wave` of block `blk`: the 8 slots of buffer `buf` summed in slot order, then the top-K epilogue
+    auto reduce = [&](int blk, unsigned buf, bool refresh) {
+        const unsigned ln = lane_id_here();
+        const unsigned char* src = smem + XCH_AREA + buf * XCH_BUF + (unsigned)wave * 1024u + ln * 16u;
+        f32x4 sum = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) sum = sum + *reinterpret_cast<const f32x4*>(src + w * XCH_WAVE);
+        if (refresh) { // minimum of the 8 class words of query 16 tn + c (what an earlier refresh brought, or 0)
+            const unsigned a0 = (unsigned)(size_t)(lds_void*)smem + THR_AREA + ((unsigned)tn * 16u + (ln & 15u)) * 32u;
+            u32x4 w0 = {0u, 0u, 0u, 0u}, w1 = w0;
 #if defined(__HIP_DEVICE_COMPILE__)
-                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(w0), "=&v"(w1) : "v"(a0) : "memory");
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(w0), "=&v"(w1) : "v"(a0) : "memory");
 #endif
-                const unsigned key = min(min(min(w0[0], w0[1]), min(w0[2], w0[3])), min(min(w1[0], w1[1]), min(w1[2], w1[3])));
-                thr = fmaxf(thr, key > 1u ? thr_decode(key - 1u) : -INFINITY);
-            }
-            const int base = blk * V3_DB + 16 * th + 4 * (int)(ln >> 4);
-            if ((int64_t)(blk + 1) * V3_DB > p.ntotal) { // ragged last block of the index (uniform)
+            const unsigned key = min(min(min(w0[0], w0[1]), min(w0[2], w0[3])), min(min(w1[0], w1[1]), min(w1[2], w1[3])));
+            thr = fmaxf(thr, key > 1u ? thr_decode(key - 1u) : -INFINITY);
+        }
+        const int base = blk * V3_DB + 16 * th + 4 * (int)(ln >> 4);
+        if ((int64_t)(blk + 1) * V3_DB > p.ntotal) { // ragged last block of the index (uniform)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if ((int64_t)(base + r) >= p.ntotal) sum[r] = -INFINITY;
-            }
-            const float mx = fmaxf(fmaxf(sum[0], sum[1]), fmaxf(sum[2], sum[3]));
-            if (__ballot(mx > thr) != 0ull) {
-                const float mark = ls[PUB - 1];
+            for (int r = 0; r < 4; ++r)
+                if ((int64_t)(base + r) >= p.ntotal) sum[r] = -INFINITY;
+        }
+        const float mx = fmaxf(fmaxf(sum[0], sum[1]), fmaxf(sum[2], sum[3]));
+        if (__ballot(mx > thr) != 0ull) {
+            const float mark = ls[PUB - 1];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float s = sum[r];
-                    if (s > thr) {
-                        list_insert<KL>(ls, li, s, base + r);
-                        thr = fmaxf(thr, ls[KL - 1]);
-                    }
+            for (int r = 0; r < 4; ++r) {
+                const float sc = sum[r];
+                if (sc > thr) {
+                    list_insert<KL>(ls, li, sc, base + r);
+                    thr = fmaxf(thr, ls[KL - 1]);
                 }
-                if (ls[PUB - 1] > mark) { // new PUB-th best of this sub-list: raise its class word, (4 split + g) & 7
-                    const unsigned cls = (4u * (unsigned)split + (ln >> 4)) & 7u;
-                    publish_umax(thr_encode(ls[PUB - 1]), ((unsigned)tn * 16u + (ln & 15u)) * 32u + 4u * cls, thr_rsrc);
-                }
+            }
+            if (ls[PUB - 1] > mark) { // new PUB-th best of this sub-list: raise its class word, (4 split + g) & 7
+                const unsigned cls = (4u * (unsigned)split + (ln >> 4)) & 7u;
+                publish_umax(thr_encode(ls[PUB - 1]), ((unsigned)tn * 16u + (ln & 15u)) * 32u + 4u * cls, thr_rsrc);
             }
         }
-        if (i + AHEAD + 1 < nb) pbase += blk_bytes;
-        stage = stage == STAGES - 1 ? 0 : stage + 1;
-        pstage = pstage == STAGES - 1 ? 0 : pstage + 1;
+    };
+    auto refresh_of = [](int i) { return i < 8 || (i & 7) == 0; };
+
+    if (PIPE) {
+        // one barrier per block; iteration i multiplies block i and reduces block i - 1 (one more iteration for the last block)
+        for (int i = 0; i <= nb && nb > 0; ++i) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PER_BLOCK) : "memory"); // this wave's share of block i has landed
+            bump(cnt_a);
+            poll(cnt_a, (unsigned)(i + 1) * WAVES);
+            refresh_thresholds(refresh_of(i)); // (issued in the extra iteration too: uniform vmcnt arithmetic)
+#pragma unroll
+            for (int t = 0; t < PPW; ++t) issue_piece(pbase, pstage, t); // block i + AHEAD into the stage block i - 1 left
+            if (i < nb) multiply(stage, (unsigned)(i & 1));
+            if (i > 0 && reducer) reduce(b0 + i - 1, (unsigned)((i - 1) & 1), refresh_of(i - 1));
+            if (i + AHEAD + 1 < nb) pbase += blk_bytes;
+            stage = stage == STAGES - 1 ? 0 : stage + 1;
+            pstage = pstage == STAGES - 1 ? 0 : pstage + 1;
+        }
+    } else {
+        for (int i = 0; i < nb; ++i) {
+            // barrier A: this wave's share of block i has landed (everything but the youngest AHEAD - 1 blocks' operations) ...
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PER_BLOCK) : "memory");
+            bump(cnt_a);
+            poll(cnt_a, (unsigned)(i + 1) * WAVES); // ... and everybody's; everybody is also done with block i - 1 (its stage, the slots)
+            refresh_thresholds(refresh_of(i));
+#pragma unroll
+            for (int t = 0; t < PPW; ++t) issue_piece(pbase, pstage, t); // block i + AHEAD into the stage block i - 1 just left
+            multiply(stage, 0u);
+            bump(cnt_b); // (a wave's LDS operations complete in order: the counter is visible after the slot)
+            if (reducer) {
+                poll(cnt_b, (unsigned)(i + 1) * WAVES);
+                reduce(b0 + i, 0u, refresh_of(i));
+            }
+            if (i + AHEAD + 1 < nb) pbase += blk_bytes;
+            stage = stage == STAGES - 1 ? 0 : stage + 1;
+            pstage = pstage == STAGES - 1 ? 0 : pstage + 1;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no DMA may outlive the workgroup's LDS allocation
 

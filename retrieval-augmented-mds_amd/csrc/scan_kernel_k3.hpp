@@ -39,7 +39,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
     constexpr int PPW = PIECES / WAVES;
     constexpr int KH = KS32 / 2;                    // k32-steps of one K half
     static_assert(KS32 % 4 == 0 && PIECES % WAVES == 0, "K halves must be whole 64-k slabs, DMA shares whole pieces");
-    static_assert(PIECES / WAVES <= KS32 / 2, "one DMA piece per step of the foreign half");
+    static_assert(2 * (PIECES / WAVES) <= KS32 / 2, "the DMA pieces are issued inside the foreign half, one per two steps");
     static_assert(KL <= 8, "8 class words vouch for 8 documents");
     constexpr int CHAIN = 2 * KH;                   // k-steps per block and wave (two document halves)
 
@@ -201,14 +201,12 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
         }
     };
 
-    auto block = [&](bool refresh, int blk, int stage, const unsigned char* nbase, int nstage, bool have_next) {
+    auto block = [&](bool refresh, int blk, int stage, const unsigned char* nbase, int nstage) {
         // pieces of the NEXT block first: their stage was released by the barrier just passed
         if (refresh) refresh_thresholds();
         if (idle_pair) {
-            if (have_next) {
 #pragma unroll
-                for (int i = 0; i < PPW; ++i) issue_piece(nbase, nstage, i);
-            }
+            for (int i = 0; i < PPW; ++i) issue_piece(nbase, nstage, i);
             arrive();
             return;
         }
@@ -237,7 +235,23 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
 #pragma unroll
                 for (int n = 0; n < NCB; ++n) acc[hpos][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[t % AD], bq[n][j], acc[hpos][n], 0, 0, 0);
                 if (t + AD < CHAIN) ar[t % AD] = lds_frag(t + AD);
-                if (have_next && hpos == 0 && j < PPW) issue_piece(nbase, nstage, j); // early: they must land by the end of this chain
+                // The pieces of the next block: early (they must have landed by the end of this block), but NOT by both waves of a
+                // SIMD at once -- the two partners (waves w and w + 4) pass the barrier together, and a piece costs its wave 100+ cycles
+                // of issue that only the partner's MFMAs can cover (the diagnostic build without the DMA, TIMING_MODE 2, runs 17 %
+                // faster: profiles/r3_pitch1024).  One piece every other step of the foreign half, the partners on alternate steps.
+                // The pieces are issued UNCONDITIONALLY (the last block re-fetches itself, see the main loop): with a second branch
+                // per site the 256-VGPR allocation spills a query fragment and reloads it in every block.
+                // TIMING_MODE 4 / 5 / 6 (diagnostics, same results): every wave in steps 0 .. PPW - 1 (the first build) / waves
+                // 0 .. 3 in steps 0 .. PPW - 1 and waves 4 .. 7 in steps PPW .. 2 PPW - 1 / every wave on the even steps.
+                if (TIMING_MODE == 4) {
+                    if (hpos == 0 && j < PPW) issue_piece(nbase, nstage, j);
+                } else if (TIMING_MODE == 5) {
+                    if (hpos == 0 && j < 2 * PPW && (j / PPW) == (wave >> 2)) issue_piece(nbase, nstage, j % PPW);
+                } else if (TIMING_MODE == 6) {
+                    if (hpos == 0 && j < 2 * PPW && (j & 1) == 0) issue_piece(nbase, nstage, j >> 1);
+                } else if (TIMING_MODE != 2) {
+                    if (hpos == 0 && j < 2 * PPW && ((j ^ (wave >> 2)) & 1) == 0) issue_piece(nbase, nstage, j >> 1); // (this spelling allocates without a spill: tools/kernel_regs.py)
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (hpos == 0) {
@@ -246,11 +260,11 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
                 unsigned char* slot = smem + XCH_AREA + wave * XCH_WAVE + lane_id_here() * 16u;
 #pragma unroll
                 for (int n = 0; n < NCB; ++n) *reinterpret_cast<f32x4*>(slot + 1024 * n) = acc[0][n];
-                bump(xcnt_mine);
+                if (TIMING_MODE != 3) bump(xcnt_mine); // (TIMING_MODE 3: diagnostic build without the pair's counter hand-shake)
             }
         }
         // the partner's partial sums for MY half
-        poll(xcnt_partner, (unsigned)(blk - b0) + 1u);
+        if (TIMING_MODE != 3) poll(xcnt_partner, (unsigned)(blk - b0) + 1u);
         f32x4 own[NCB];
         {
             const unsigned char* slot = smem + XCH_AREA + (wave ^ 1) * XCH_WAVE + lane_id_here() * 16u;
@@ -298,8 +312,10 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
     for (int i = 0; i < nb; ++i) {
         arrivals_needed += WAVES;
         poll(cnt_lds, arrivals_needed); // every share of block i landed; everyone is done with block i - 1
-        const bool have_next = i + 1 < nb;
-        block(i < 8 || (i & 7) == 0, b0 + i, i & 1, first + (int64_t)(i + 1) * blk_bytes, (i + 1) & 1, have_next);
+        // (the last block of the range re-fetches ITSELF into the free stage instead of a next block: the pieces are issued
+        // unconditionally, the MFMA chain stays one basic block)
+        const unsigned char* nbase = first + (int64_t)(i + 1 < nb ? i + 1 : i) * blk_bytes;
+        block(i < 8 || (i & 7) == 0, b0 + i, i & 1, nbase, (i + 1) & 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
