@@ -96,7 +96,9 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
     constexpr unsigned XCH_AREA = THR_AREA + PAIRS * THR_PAIR;
     constexpr unsigned XCH_WAVE = NCB * 1024u;
     constexpr unsigned CNT_AREA = XCH_AREA + WAVES * XCH_WAVE;
-    static_assert(CNT_AREA + 64 <= 160 * 1024, "LDS budget");
+    constexpr unsigned PF_AREA = CNT_AREA + 64;     // 256 B nobody reads: where the L2 prefetch of a later block lands
+    constexpr bool PREFETCH = TIMING_MODE == 7 || TIMING_MODE == 8;
+    static_assert(PF_AREA + 256 <= 160 * 1024, "LDS budget");
     // p.gthr = [query tile][pair][48 queries][8 words]: both waves of a pair publish into the same 1.5 KiB
     const __amdgpu_buffer_rsrc_t thr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(reinterpret_cast<unsigned char*>(p.gthr) + (int64_t)qt * (PAIRS * THR_PAIR)), 0, PAIRS * THR_PAIR, 0x00020000);
@@ -149,9 +151,20 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
             asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, 1\n\tds_add_u32 %0, %1" : "=&v"(ta), "=&v"(tb) : "s"(saddr) : "memory");
 #endif
     };
-    auto arrive = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // 2-stage ring: this wave's share of the NEXT block has landed
+    auto arrive = [&](bool in_loop = true) {
+        // 2-stage ring: this wave's share of the NEXT block has landed (the one younger operation that may still be in flight is
+        // the block's L2 prefetch, issued after the pieces)
+        if (PREFETCH && in_loop) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bump(cnt_lds);
+    };
+    // One dword of each 128-B line of a block PF_DIST blocks ahead, 64 lines per wave, into the dummy area: the L2 miss of that
+    // line is taken here, 2+ blocks before its DMA piece is issued, instead of inside the 2-stage ring's one-block window.
+    constexpr int PF_DIST = TIMING_MODE == 8 ? 6 : 3;
+    auto prefetch_block = [&](const unsigned char* blk_base) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void*)blk_base, 0, (int)(V3_DB * row_bytes), 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + PF_AREA), 4, lane_id_here() * 128u, wave * 8192, 0, 0);
     };
     auto poll = [&](unsigned addr, unsigned need) {
         for (int spin = 0;; ++spin) {
@@ -201,12 +214,13 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
         }
     };
 
-    auto block = [&](bool refresh, int blk, int stage, const unsigned char* nbase, int nstage) {
+    auto block = [&](bool refresh, int blk, int stage, const unsigned char* nbase, int nstage, const unsigned char* pbase) {
         // pieces of the NEXT block first: their stage was released by the barrier just passed
         if (refresh) refresh_thresholds();
         if (idle_pair) {
 #pragma unroll
             for (int i = 0; i < PPW; ++i) issue_piece(nbase, nstage, i);
+            if (PREFETCH) prefetch_block(pbase);
             arrive();
             return;
         }
@@ -243,6 +257,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
                 // per site the 256-VGPR allocation spills a query fragment and reloads it in every block.
                 // TIMING_MODE 4 / 5 / 6 (diagnostics, same results): every wave in steps 0 .. PPW - 1 (the first build) / waves
                 // 0 .. 3 in steps 0 .. PPW - 1 and waves 4 .. 7 in steps PPW .. 2 PPW - 1 / every wave on the even steps.
+                if (PREFETCH && hpos == 1 && j == 0) prefetch_block(pbase);
                 if (TIMING_MODE == 4) {
                     if (hpos == 0 && j < PPW) issue_piece(nbase, nstage, j);
                 } else if (TIMING_MODE == 5) {
@@ -308,14 +323,15 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
         for (int i = 0; i < PPW; ++i) issue_piece(first, 0, i);
     }
     __syncthreads();
-    if (nb > 0) arrive(); // this wave's share of block 0 has landed
+    if (nb > 0) arrive(false); // this wave's share of block 0 has landed
     for (int i = 0; i < nb; ++i) {
         arrivals_needed += WAVES;
         poll(cnt_lds, arrivals_needed); // every share of block i landed; everyone is done with block i - 1
         // (the last block of the range re-fetches ITSELF into the free stage instead of a next block: the pieces are issued
         // unconditionally, the MFMA chain stays one basic block)
         const unsigned char* nbase = first + (int64_t)(i + 1 < nb ? i + 1 : i) * blk_bytes;
-        block(i < 8 || (i & 7) == 0, b0 + i, i & 1, nbase, (i + 1) & 1);
+        const int ipf = i + PF_DIST < nb ? i + PF_DIST : nb - 1;
+        block(i < 8 || (i & 7) == 0, b0 + i, i & 1, nbase, (i + 1) & 1, first + (int64_t)ipf * blk_bytes);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
