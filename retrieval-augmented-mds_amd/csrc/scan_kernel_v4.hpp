@@ -128,6 +128,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
     const unsigned char* docs_b = reinterpret_cast<const unsigned char*>(p.docs);
     const int64_t row_bytes = (int64_t)p.ld * 2;
     auto issue_piece = [&](const unsigned char* blk_base, int stage, int i) {
+        if (TIMING_MODE == 6 || TIMING_MODE == 8) return; // diagnostic builds (results are wrong): the ring is never filled
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void*)blk_base, 0, (int)(V3_DB * row_bytes), 0x00020000);
         const int pc = wave + WAVES * i;
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
     };
     auto wait_all = [&]() {
         arrivals_needed += WAVES;
+        if (TIMING_MODE == 7) return; // diagnostic build (results are wrong): nobody waits for the block's arrivals
         for (int spin = 0;; ++spin) {
             unsigned v = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
     // against queries c (n = 0) and 16 + c (n = 1).  No synchronisation in here: at mid-block the partner
     // wave's MFMAs keep the matrix pipe busy while this wave runs the few instructions of the pre-test.
     auto epilogue_half = [&](f32x4 (&acc)[2], int blk, int half) {
-        if (TIMING_MODE == 1) { // diagnostic build (results are wrong): no epilogue at all
+        if (TIMING_MODE == 1 || TIMING_MODE == 8) { // diagnostic builds (results are wrong): no epilogue at all
 #if defined(__HIP_DEVICE_COMPILE__)
             asm volatile("" ::"v"(acc[0]), "v"(acc[1]));
 #endif
@@ -252,11 +254,14 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[t % AD], bq[0][s], acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[t % AD], bq[1][s], acc[1], 0, 0, 0);
                 if (t + AD < STEPS) ar[t % AD] = lds_frag(t + AD);
-                if ((t % (STEPS / PPW)) == (STEPS / PPW) / 2) issue_piece(pbase, pstage, t / (STEPS / PPW));
+                // TIMING_MODE 9 (experiment, same results): the two waves of a SIMD (w, w + 4) issue their pieces half a period apart
+                if (TIMING_MODE == 9) {
+                    if ((t % (STEPS / PPW)) == ((STEPS / PPW) / 2) * (1 - (wave >> 2))) issue_piece(pbase, pstage, t / (STEPS / PPW));
+                } else if ((t % (STEPS / PPW)) == (STEPS / PPW) / 2) issue_piece(pbase, pstage, t / (STEPS / PPW));
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (half == 1) arrive(); // all LDS reads of this block are done; the epilogue runs un-synchronised
-            if (half == 1 && refresh && TIMING_MODE != 1) {
+            if (half == 1 && refresh && TIMING_MODE != 1 && TIMING_MODE != 8) {
                 // minimum of the 8 class words of queries c and 16 + c (what an earlier block's DMA brought, or 0);
                 // inline asm, one query at a time: see scan_kernel_v3.hpp
                 const unsigned thr_addr = thr_addr_of(lane_id_here());
@@ -307,6 +312,10 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
     if (nb > 0) arrive();
     for (int i = 0; i < nb; ++i) {
         wait_all();
+        // TIMING_MODE 10 / 11 / 12 (experiment, same results): the second wave of each SIMD starts its block 64 / 128 / 192 cycles
+        // late, so that the two waves' epilogues (an MFMA -> VALU dependency stall + ~10 dependent instructions per half, which both
+        // reach at the same moment when they leave the barrier together) fall into each other's MFMA chains
+        if (TIMING_MODE >= 10 && TIMING_MODE <= 12 && wave >= 4) __builtin_amdgcn_s_sleep(TIMING_MODE - 9);
         block(i < 8 || (i & 7) == 0, b0 + i, stage, pbase, pstage); // refresh schedule: scan_kernel_v3.hpp
         if (i + AHEAD + 1 < nb) pbase += blk_bytes;
         stage = stage == STAGES - 1 ? 0 : stage + 1;
