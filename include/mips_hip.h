@@ -259,7 +259,9 @@ int mips_rows_max_sumsq_device(const float* x_device, int64_t n, int64_t d, doub
 /* Tuning knobs of the scan launch (0 = automatic): "nsplit" = number of index splits (rounded up
  * to a multiple of 8), "qgroups" = query-tile groups per XCD octet (1, 2, 4 or 8), "variant" = scan kernel (1 = 128x128
  * register-staged tiles, 3 = query-stationary on the 32x32x16 MFMA shape, 4 = query-stationary on the
- * 16x16x32 shape (d padding to 384 .. 768, k <= 5)).  Results never depend on these four; only speed does.
+ * 16x16x32 shape (d padding to 384 .. 768, k <= 5), 7 = wave pairs splitting K at row pitch 1024 (k <= 5); 5 and 6 name
+ * measured alternatives that exist in the A/B build of tools/ab.py only and are ignored here).  Results never depend on
+ * these four; only speed does.
  * "margin_check" (0 .. 4) selects what happens to queries whose candidate pool is not provably wide enough: see
  * mips_index_margin_stats.  "resolve_budget" (default 0 = 1024): flagged queries one search settles at most.
  * "f32_fast" (fp32-exact index): 0 = always the three-segment scan, 1 (default) = two-stage search in every call that certifies

@@ -19,8 +19,10 @@
 #include "scan_kernel_f8.hpp"
 #include "scan_kernel_f8x.hpp"
 #include "scan_kernel_v4.hpp"
+#ifdef MIPS_EXPERIMENTAL // measured alternatives that never became a default (profiles/r2_v5_64q, r2_pitch1024): A/B library only
 #include "scan_kernel_v5.hpp"
 #include "scan_kernel_ks.hpp"
+#endif
 #include "scan_kernel_k3.hpp"
 #include "scan_kernel_e8.hpp"
 #include "tiny_search.hpp"
@@ -546,7 +548,12 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // scan_kernel_v5 (64 stationary queries per wave, one wave per SIMD): row pitches whose 64-k slabs divide evenly
     // among 4 waves
     const bool v5_shape = (ix->ld == 768 || ix->ld == 512) && KL == 8 && ix->esize == 2 && ix->plane == 0;
+#ifdef MIPS_EXPERIMENTAL
     const bool want_v5 = variant == 5 && v5_shape;
+#else
+    const bool want_v5 = false; // ("variant" = 5 / 6 select kernels of the A/B library only; the shipped library ignores them)
+    (void)v5_shape;
+#endif
     const bool v4_forced = variant == 4 && v4_shape;
     const bool v4_auto = variant == 0 && ix->opt_sub == 0 && v4_shape;
     if (variant != 1 && variant != 3) variant = 3; // (4 / 5 were decided above; the rest of the function only knows 1 and 3)
@@ -580,7 +587,11 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // 6), not the default: measured 30.6 vs 31.3 ms at 2^22 x 1024 against the one-wave-per-SIMD scan_kernel_v3
     // configuration (profiles/r2_pitch1024) -- both sit on the L2 -> LDS fill of 128 stationary queries per CU
     const bool ks_shape = ix->ld == 1024 && KL == 8 && ix->esize == 2 && ix->plane == 0;
+#ifdef MIPS_EXPERIMENTAL
     const bool want_ks = ks_shape && ix->opt_variant == 6;
+#else
+    const bool want_ks = false;
+#endif
     // scan_kernel_k3 (round 3): the wave pairs of scan_kernel_ks with 48 queries each -- 192 stationary queries per CU, a third
     // less L2 -> LDS fill per flop, which is what bounds pitch 1024.  Default there once several 192-query tiles share the
     // document stream (the MFMA-bound regime); smaller searches keep the 128-query configuration ("variant" = 7 / 3 force one)
@@ -728,6 +739,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             if (rc3) return rc3;
             set_kernel_name(ix, "mips::scan_kernel_k3<%d, 32, 2, 0>", K3_KLL);
         }
+#ifdef MIPS_EXPERIMENTAL
     } else if (want_ks) {
         if constexpr (KL == 8) {
             const int lds = 2 * mips::V3_DB * ix->ld * 2 + 8 * 1024 + 8 * 2048 + 64; // ring + class-word copies + exchange slots + counters
@@ -746,17 +758,15 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
                 return MIPS_OK;
             };
             int rc2;
-#ifdef MIPS_EXPERIMENTAL
             if (ix->ld == 768 && ix->opt_sub == 8) rc2 = go5(mips::scan_kernel_v5<V4_KLL, 24, 2, 1>); // timing only: no epilogue
             else if (ix->ld == 768 && ix->opt_sub == 21) rc2 = go5(mips::scan_kernel_v5<V4_KLL, 24, 3>); // prefetch depth 3
             else if (ix->ld == 768 && ix->opt_sub == 22) rc2 = go5(mips::scan_kernel_v5<V4_KLL, 24, 4>); // prefetch depth 4
-            else
-#endif
-            if (ix->ld == 768) rc2 = go5(mips::scan_kernel_v5<V4_KLL, 24>);
+            else if (ix->ld == 768) rc2 = go5(mips::scan_kernel_v5<V4_KLL, 24>);
             else rc2 = go5(mips::scan_kernel_v5<V4_KLL, 16>);
             if (rc2) return rc2;
             set_kernel_name(ix, "mips::scan_kernel_v5<%d, %d, 2, 0>", V4_KLL, ix->ld / 32);
         }
+#endif
     } else if (want_v4) {
         if constexpr (KL == 8 || KL == 16 || KL == 32) {
 #ifdef MIPS_EXPERIMENTAL

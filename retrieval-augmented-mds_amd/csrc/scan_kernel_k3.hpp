@@ -22,7 +22,6 @@
 #include "scan_kernel.hpp"
 #include "scan_kernel_v3.hpp"
 #include "scan_kernel_v4.hpp"
-#include "scan_kernel_ks.hpp"
 
 namespace mips {
 

@@ -1085,7 +1085,7 @@ def test_experimental_scan_variants_are_bit_identical():
     assert np.array_equal(ref_i[:64].cpu().numpy(), ei) and np.array_equal(ref_s[:64].cpu().numpy(), es)
     for params in ({"variant": 4}, {"variant": 3}, {"variant": 1}, {"variant": 3, "nsplit": 40}, {"variant": 3, "qgroups": 2},
                    {"variant": 4, "nsplit": 8}, {"variant": 4, "qgroups": 4},
-                   {"variant": 5}, {"variant": 5, "nsplit": 8}, {"variant": 5, "nsplit": 40}):   # 5 = 64 stationary queries per wave
+                   {"variant": 5}, {"variant": 5, "nsplit": 40}):   # 5 / 6 select kernels of the A/B library; the shipped one ignores them
         for name in ("variant", "nsplit", "qgroups"):
             ix.set_param(name, params.get(name, 0))
         s, i = ix.search(q, k)
@@ -1776,10 +1776,11 @@ def test_fused_hook_search_prepare_search_ignore_in_one_call(tmp_path, metric, n
 
 
 def test_pitch_1024_k_split_kernel_is_bit_identical():
-    """Row pitch 1024: scan_kernel_v3's one-wave-per-SIMD configuration ("variant" = 3; the default up to 256 queries),
-    scan_kernel_ks ("variant" = 6: a wave pair splits K, partial sums meet in LDS) and scan_kernel_k3 ("variant" = 7, the
-    default beyond 256 queries: the same pairs with 48 queries each, 192-query tiles, sub-lists of 4) return the same bits --
-    and the oracle's -- on ragged sizes, single- and multi-tile query counts, forced split counts, ties."""
+    """Row pitch 1024: scan_kernel_v3's one-wave-per-SIMD configuration ("variant" = 3; the default up to 256 queries) and
+    scan_kernel_k3 ("variant" = 7, the default beyond 256 queries: wave pairs split K, partial sums meet in LDS, 48 queries per
+    pair, 192-query tiles, sub-lists of 4) return the same bits -- and the oracle's -- on ragged sizes, single- and multi-tile
+    query counts, forced split counts, ties.  (scan_kernel_ks, "variant" = 6, the first K-split kernel, lives in the A/B library
+    of tools/ab.py only; the shipped library ignores the value and the default kernels answer.)"""
     for n, nq, d, k in ((70001, 300, 1024, 5), (150001, 700, 1000, 5), (64 * 37 + 5, 129, 800, 4), (5000, 40, 1024, 1), (40000, 193, 1024, 5)):
         ix = ram.MipsIndex(d)
         ix.add_synthetic(n, row0=0, seed=171, kind=synth.KIND_GAUSS)
@@ -1789,7 +1790,9 @@ def test_pitch_1024_k_split_kernel_is_bit_identical():
         x = synth.generate(171, 0, n, d, synth.KIND_GAUSS)
         es, ei = orc.search_exact(q.float().cpu().numpy(), x, k)
         assert np.array_equal(ref_i.cpu().numpy(), ei) and np.array_equal(ref_s.cpu().numpy(), es)
-        for variant, name in ((6, "scan_kernel_ks"), (7, "scan_kernel_k3<"), (3, "scan_kernel_v3")):
+        for variant, name in ((6, "scan_kernel_k"), (7, "scan_kernel_k3<"), (3, "scan_kernel_v3")):
+            if variant == 6 and nq <= 256:
+                continue                                            # (ignored by the shipped library: the default kernel, scan_kernel_v3 here)
             ix.set_param("variant", variant)
             for ns in (0, 8, 40):
                 ix.set_param("nsplit", ns)
@@ -1805,7 +1808,7 @@ def test_pitch_1024_k_split_kernel_is_bit_identical():
     x[333] = x[700]
     ql[0] = x[700]
     es, ei = orc.search_exact_bruteforce(ql, x, 5)
-    for variant, name in ((6, "scan_kernel_ks"), (7, "scan_kernel_k3<"), (0, "scan_kernel_k3")):
+    for variant, name in ((6, "scan_kernel_k"), (7, "scan_kernel_k3<"), (0, "scan_kernel_k3")):
         ix = _index(x)
         ix.set_param("variant", variant)
         s, i = ix.search(ql, 5)

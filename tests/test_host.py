@@ -398,3 +398,27 @@ def test_faiss_shim_surface_without_a_gpu(tmp_path, monkeypatch):
     import importlib.util
     assert importlib.util.find_spec("faiss") is not None      # what HF's `_has_faiss` asks
     _s.modules.pop("faiss", None)
+
+
+def test_no_shipped_kernel_spills_or_uses_scratch():
+    """Every gfx950 kernel of the built library allocates without a spill and without a private segment (a scratch reload
+    behind LDS-DMA pieces drains the ring: the register budgets of the scan kernels are set to the last VGPR, and a small edit
+    can tip one over -- tools/kernel_regs.py reads the code object's notes, no GPU needed), and the kernels that only exist for
+    A/B measurements (`sub` instances, scan_kernel_v5 / scan_kernel_ks) are not in the shipped library."""
+    import sys
+
+    ram.build()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    try:
+        import kernel_regs
+    finally:
+        sys.path.pop(0)
+    if not os.path.exists(os.path.join(kernel_regs.LLVM, "clang-offload-bundler")):
+        pytest.skip("llvm tools of the ROCm image not found")
+    ks = kernel_regs.kernels()
+    assert len(ks) > 100
+    bad = [(k["demangled"], k["spill"], k["scratch"]) for k in ks if k["spill"] or k["scratch"]]
+    assert not bad, bad
+    names = " ".join(k["demangled"] for k in ks)
+    assert "scan_kernel_v4<" in names and "scan_kernel_k3<" in names and "scan_kernel_e8<" in names and "tiny_search_kernel<" in names
+    assert "scan_kernel_v5<" not in names and "scan_kernel_ks<" not in names
