@@ -586,7 +586,13 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // scan_kernel_ks (K split over a wave pair, two waves per SIMD): row pitch 1024, k <= 5.  Selectable ("variant" =
     // 6), not the default: measured 30.6 vs 31.3 ms at 2^22 x 1024 against the one-wave-per-SIMD scan_kernel_v3
     // configuration (profiles/r2_pitch1024) -- both sit on the L2 -> LDS fill of 128 stationary queries per CU
-    const bool ks_shape = ix->ld == 1024 && KL == 8 && ix->esize == 2 && ix->plane == 0;
+    // (round 3, later: pools of 16 / 32 out of scan_kernel_k3's sub-lists, every sub-list vouching for its 2nd / 4th best -- the
+    // "optimistic" pools of scan_kernel_v4 at this pitch: first stage of the fp32-exact search at d in (768, 1024], bf16 searches
+    // with 8 <= k <= 29, and k <= 5 on large indexes, where the MFMA error bound at K = 1024 reaches the 8th best score of one
+    // query in a few thousand and a flagged query costs a pass over the index)
+    const bool k3_opt = ix->optimistic && ix->rescan_depth == 0 && (KL == 16 || KL == 32) && ix->opt_variant == 0 && ix->opt_sub == 0 &&
+                        ix->ld == 1024 && ix->esize == 2 && ix->plane == 0 && !ix->mixed && nq > 256;
+    const bool ks_shape = ix->ld == 1024 && (KL == 8 || k3_opt) && ix->esize == 2 && ix->plane == 0;
 #ifdef MIPS_EXPERIMENTAL
     const bool want_ks = ks_shape && ix->opt_variant == 6;
 #else
@@ -595,7 +601,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // scan_kernel_k3 (round 3): the wave pairs of scan_kernel_ks with 48 queries each -- 192 stationary queries per CU, a third
     // less L2 -> LDS fill per flop, which is what bounds pitch 1024.  Default there once several 192-query tiles share the
     // document stream (the MFMA-bound regime); smaller searches keep the 128-query configuration ("variant" = 7 / 3 force one)
-    const bool want_k3 = ks_shape && (ix->opt_sub == 0 || (ix->opt_sub >= 61 && ix->opt_sub <= 68)) && (ix->opt_variant == 7 || (ix->opt_variant == 0 && nq > 256));
+    const bool want_k3 = k3_opt || (ks_shape && (ix->opt_sub == 0 || (ix->opt_sub >= 61 && ix->opt_sub <= 68)) && (ix->opt_variant == 7 || (ix->opt_variant == 0 && nq > 256)));
     constexpr int K3_KLL = 4; // entries per sub-list (the third accumulator set is paid for with shorter lists)
     // (a variant on 16-document stages -- 4-stage ring, three blocks in flight, one barrier per 16 documents -- was built and
     // measured 18 % SLOWER, 34.8 vs 29.5 ms at 2^22 x 1024: profiles/r3_pitch1024/README.md; what parks the waves is the barrier
@@ -714,7 +720,8 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         set_kernel_name(ix, "mips::scan_kernel_e8<6, %d, %d, %d, %s, %d, %s>", ix->ld, e8_ncb, e8_stages(ix->ld, e8_ncb), nt ? "true" : "false", PUB,
                         e8_pipelined(ix->ld, e8_ncb) ? "true" : "false");
     } else if (want_k3) {
-        if constexpr (KL == 8) {
+        if constexpr (KL == 8 || KL == 16 || KL == 32) {
+            constexpr int K3_PUB = KL / 8; // pool of 8 PUB candidates: every sub-list vouches for its PUB-th best
             const int lds = 2 * mips::V3_DB * ix->ld * 2 + 4 * 1536 + 8 * 3072 + 64 + 256; // ring + the pairs' class-word copies + exchange slots + counters
             auto gok3 = [&](auto kern) -> int {
                 HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -735,9 +742,9 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             else if (ix->opt_sub == 68) rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 8>); // ... six blocks ahead
             else
 #endif
-            rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2>);
+            rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 0, K3_PUB>);
             if (rc3) return rc3;
-            set_kernel_name(ix, "mips::scan_kernel_k3<%d, 32, 2, 0>", K3_KLL);
+            set_kernel_name(ix, "mips::scan_kernel_k3<%d, 32, 2, 0, %d>", K3_KLL, K3_PUB);
         }
 #ifdef MIPS_EXPERIMENTAL
     } else if (want_ks) {
@@ -1963,8 +1970,20 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
         }
         // (pools of 32, not 16: with the 16th best score as the bound 30 of 4096 Gaussian queries went to the second stage, and
         // a second stage of even one query tile costs more than stage 1 saved -- 22 ms per call instead of 5.4)
+        // bf16 rows at pitch 1024, k <= 5, a large index, a call that certifies: pool of 16 (scan_kernel_k3 with every sub-list
+        // vouching for its 2nd best).  The MFMA error bound at K = 1024 (0.14 on unit-variance data) reaches from the 5th exact score
+        // to the 8th best approximate one for one Gaussian query in ~3000 at 2^22 rows, and each flagged query costs a pass over the
+        // index (3 ms there); the 16th best is out of reach.  Small indexes keep the pool of 8 (their exact pass is cheap).
+        bool deep_1024 = !fast && k <= 5 && ix->plane == 0 && ix->esize == 2 && !ix->mixed && ix->ld == 1024 && nq > 256 && ix->ntotal >= (1ll << 21) &&
+                         ix->opt_margin != 0 && !split && (!out_dev || ix->opt_margin >= 2) && ix->opt_f32_fast != 0;
+        if (deep_1024 && ix->fast_skip > 0) {
+            --ix->fast_skip;
+            deep_1024 = false;
+        }
         if (fast && hi_long) {
             rc = scan_and_finish<32>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, tail_st, split, true);
+        } else if (k <= 5 && deep_1024) {
+            rc = scan_and_finish<16>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, tail_st, split, false, true);
         } else if (k <= 5) {
             rc = scan_and_finish<8>(ix, nq, k, d_s, d_i, packed, idx_offset, out_dev, st, tail_st, split, fast);
         } else if (k <= 7) { // k + 1 = 6 is what Mips.search fetches for top_k = 5 with ignore_indexes (mips.py:388-398)
@@ -1973,8 +1992,8 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
             // bf16 index, a call that certifies, 8 <= k <= 29: pool of 32 out of the 16x16x32 kernel's sub-lists (see
             // mips_index::optimistic; round 3: k = 14 .. 29 as well -- the class words vouch for 32 documents, what the
             // sub-lists of 6 may have dropped is bounded, the margin check decides per query).  Otherwise true K' = 16 / 32 lists.
-            bool opt = ix->plane == 0 && ix->esize == 2 && ix->opt_margin != 0 && !split && (!out_dev || ix->opt_margin >= 2) &&
-                       ix->opt_f32_fast != 0 && ix->ld % 128 == 0 && ix->ld >= 384 && ix->ld <= 768;
+            bool opt = ix->plane == 0 && ix->esize == 2 && !ix->mixed && ix->opt_margin != 0 && !split && (!out_dev || ix->opt_margin >= 2) &&
+                       ix->opt_f32_fast != 0 && ((ix->ld % 128 == 0 && ix->ld >= 384 && ix->ld <= 768) || (ix->ld == 1024 && nq > 256));
             if (opt && ix->fast_skip > 0) {
                 --ix->fast_skip;
                 opt = false;

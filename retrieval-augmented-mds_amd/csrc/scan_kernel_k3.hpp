@@ -25,8 +25,12 @@
 
 namespace mips {
 
-template <int KL, int KS32, int AD, int TIMING_MODE = 0>
+// PUB: every sub-list publishes (vouches for) its PUB-th best entry, so the 8 class words of a query stand for 8 PUB documents:
+// the pool selected from the lists may be 8 PUB deep (8 / 16 / 32 candidates: mips_hip.hip, "optimistic" pools and the first
+// stage of the fp32-exact search at row pitch 1024), as scan_kernel_v4's PUB.
+template <int KL, int KS32, int AD, int TIMING_MODE = 0, int PUB = 1>
 __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
+    static_assert(PUB >= 1 && PUB <= KL, "a sub-list vouches for one of its own entries");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WAVES = 8;
     constexpr int PAIRS = 4;
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
             const int base = blk * V3_DB + 16 * role + 4 * (int)(ln >> 4);
 #pragma unroll
             for (int n = 0; n < NCB; ++n) {
-                const float mark = ls[n][0];
+                const float mark = ls[n][PUB - 1];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float s = acc[n][r];
@@ -205,9 +209,9 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
                         thr[n] = fmaxf(thr[n], ls[n][KL - 1]);
                     }
                 }
-                if (ls[n][0] > mark) { // new best of this sub-list: raise its class word, (4 split + g) & 7
+                if (ls[n][PUB - 1] > mark) { // new PUB-th best of this sub-list: raise its class word, (4 split + g) & 7
                     const unsigned cls = (4u * (unsigned)split + (ln >> 4)) & 7u;
-                    publish_umax(thr_encode(ls[n][0]), (unsigned)pair * THR_PAIR + (16u * n + (ln & 15u)) * 32u + 4u * cls, thr_rsrc);
+                    publish_umax(thr_encode(ls[n][PUB - 1]), (unsigned)pair * THR_PAIR + (16u * n + (ln & 15u)) * 32u + 4u * cls, thr_rsrc);
                 }
             }
         }

@@ -930,8 +930,8 @@ def test_f32_exact_two_stage_search(n, nq, d, k, metric):
     ix.add(x[n // 3:])
     s, i = ix.search(q, k)
     assert not ix.last_kernel.startswith("mips::scan_kernel<"), ix.last_kernel   # a query-stationary bf16 kernel, pitch 1024 included
-    if d > 768:                                                   # (round 3: true K' = 32 lists exist at pitch 1024)
-        assert ix.last_kernel.startswith("mips::scan_kernel_v3<32, 64, 1, 4"), ix.last_kernel
+    if d > 768:   # (round 3: pools of 32 at pitch 1024 -- scan_kernel_k3's sub-lists beyond 256 queries, true K' = 32 lists below)
+        assert ix.last_kernel.startswith("mips::scan_kernel_k3<4, 32, 2, 0, 4>" if nq > 256 else "mips::scan_kernel_v3<32, 64, 1, 4"), ix.last_kernel
     assert np.array_equal(i, ei) and np.array_equal(s, es)
     st = ix.margin_stats()
     assert st["flagged"] >= 0 and st["rescanned"] == st["flagged"] and st["unresolved"] == 0
@@ -2186,7 +2186,7 @@ def test_real_hf_dataset_reaches_the_index_the_way_the_reference_does(tmp_path, 
 
 
 @pytest.mark.parametrize("n,nq,d,k", [(60000, 300, 768, 20), (40000, 130, 640, 29), (50000, 300, 1024, 10), (30000, 70, 1000, 25),
-                                       (30000, 40, 1024, 14), (20000, 300, 900, 5)])
+                                       (30000, 40, 1024, 14), (20000, 300, 900, 5), (45000, 513, 1000, 25), (64 * 43 + 9, 257, 1024, 13)])
 def test_wide_k_pools_and_pitch_1024_lists(n, nq, d, k):
     """Round 3: (1) k = 14 .. 29 at row pitch 384 .. 768 take the optimistic pools of 32 (16x16x32 kernel, every sub-list vouching
     for its 4th best) like k = 8 .. 13 did; (2) row pitch 1024 has true K' = 16 / 32 lists on the query-stationary 4-wave kernel:
@@ -2200,6 +2200,8 @@ def test_wide_k_pools_and_pitch_1024_lists(n, nq, d, k):
     name = ix.last_kernel
     if k >= 8 and d <= 768:
         assert name.startswith("mips::scan_kernel_v4") and name.endswith(", 4>"), name
+    elif k >= 8 and nq > 256:   # pools of 32 out of scan_kernel_k3's sub-lists (every sub-list vouches for its 4th best)
+        assert name.startswith("mips::scan_kernel_k3<4, 32, 2, 0, 4>"), name
     elif k >= 8:
         assert name.startswith(f"mips::scan_kernel_v3<{16 if k <= 13 else 32}, 64, 1, 4"), name
     assert np.array_equal(i, ei) and np.array_equal(s, es)
@@ -2220,6 +2222,43 @@ def test_wide_k_pools_and_pitch_1024_lists(n, nq, d, k):
     st = f.margin_stats()
     assert st["unresolved"] == 0 and st["flagged"] <= max(2, nq // 8), st
     assert np.array_equal(i2.cpu().numpy(), fi) and np.array_equal(s2.cpu().numpy(), fs)
+
+
+def test_pitch_1024_deep_pool_on_large_indexes():
+    """bf16 rows at pitch 1024, k <= 5, 2^21 rows or more, more than 256 queries: the candidate pool is 16 deep (scan_kernel_k3
+    with every sub-list vouching for its 2nd best) so that the MFMA error bound at K = 1024 no longer reaches from the k-th exact
+    score to the pool's edge (with the pool of 8 one Gaussian query in a few thousand is flagged there, and each costs a pass over
+    the index).  Same bits as the pool-of-8 search ("optimistic" = 0) and as the brute-force oracle on a sample of the queries'
+    neighbourhoods; nothing flagged on Gaussian data."""
+    n, d, nq, k = (1 << 21) + 77, 1024, 1200, 5
+    ix = ram.MipsIndex(d)
+    ix.add_synthetic(n, row0=0, seed=synth.SEED_DOCS, kind=synth.KIND_GAUSS)
+    q = ram.synth_fill(nq, d, 0, synth.SEED_QUERIES, synth.KIND_GAUSS)
+    s, i = ix.search(q, k)
+    assert ix.last_kernel.startswith("mips::scan_kernel_k3<4, 32, 2, 0, 2>"), ix.last_kernel
+    st = ix.margin_stats(synchronize=True)
+    assert st["flagged"] <= 1 and st["unresolved"] == 0, st
+    ix.set_param("optimistic", 0)
+    s8, i8 = ix.search(q, k)
+    assert ix.last_kernel.startswith("mips::scan_kernel_k3<4, 32, 2, 0, 1>"), ix.last_kernel
+    assert ix.margin_stats(synchronize=True)["unresolved"] == 0
+    assert torch.equal(i, i8) and torch.equal(s, s8)
+    ix.set_param("optimistic", 1)
+    hs, hi = ix.search(q.float().cpu().numpy()[:300], k)              # 300 queries, host buffers: same rows
+    assert np.array_equal(hi, i[:300].cpu().numpy()) and np.array_equal(hs, s[:300].cpu().numpy())
+    # the returned scores are the canonical scores of the returned rows, and no row of a 200 000-row window beats the k-th
+    ii = i[:8].cpu().numpy()
+    rows = np.unique(ii.ravel())
+    xr = np.stack([synth.generate(synth.SEED_DOCS, int(r), 1, d, synth.KIND_GAUSS)[0] for r in rows])
+    q8 = q[:8].float().cpu().numpy()
+    es, ei = orc.search_exact(q8, xr, k)
+    assert np.array_equal(rows[ei], ii) and np.array_equal(es, s[:8].cpu().numpy())
+    w0 = 700001
+    xw = synth.generate(synth.SEED_DOCS, w0, 200000, d, synth.KIND_GAUSS)
+    ws, wi = orc.search_exact(q8, xw, 1)
+    for t in range(8):
+        assert ws[t, 0] <= s[t, k - 1].item() or (w0 + wi[t, 0]) in ii[t]
+    ix.check()
 
 
 # ------------------------------------------------------------------ round 3: BASELINE config 5 as worded -- e4m3 documents, bf16 queries
