@@ -2221,7 +2221,12 @@ int mips_index_set_param(mips_index_t* ix, const char* name, int64_t value) {
     const std::string n(name);
     if (n == "nsplit") ix->opt_nsplit = (int)value;
     else if (n == "qgroups") ix->opt_qgroups = (int)value;
-    else if (n == "variant") ix->opt_variant = (int)value;
+    else if (n == "variant") {
+        ix->opt_variant = (int)value;
+#ifndef MIPS_EXPERIMENTAL
+        if (value == 5 || value == 6) ix->opt_variant = 0; // (kernels of the A/B build only: the automatic choice answers)
+#endif
+    }
     else if (n == "tiny") ix->opt_tiny = value == 2 ? 2 : value != 0 ? 1 : 0; // 2: one launch, fall-back paths forced (tests)
     else if (n == "resolve") ix->opt_resolve = value != 0 ? 1 : 0;
     else if (n == "f32_fast" || n == "optimistic") { // (one switch: two-stage fp32 search and optimistic pools, include/mips_hip.h)

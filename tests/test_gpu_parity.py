@@ -2210,7 +2210,8 @@ def test_wide_k_pools_and_pitch_1024_lists(n, nq, d, k):
     assert np.array_equal(di.cpu().numpy(), ei) and np.array_equal(ds.cpu().numpy(), es) and ix.margin_stats()["unresolved"] == 0
     # the fp32-exact index of the same width: two-stage search with pools of 32 at every pitch
     rng = np.random.default_rng(n)
-    xf = (x[:20000] * rng.uniform(0.5, 2.0, (20000, 1))).astype(np.float32)
+    nf = min(n, 20000)
+    xf = (x[:nf] * rng.uniform(0.5, 2.0, (nf, 1))).astype(np.float32)
     qf = (q * rng.uniform(0.5, 2.0, (nq, 1))).astype(np.float32)
     fs, fi = orc.search_exact(qf, xf, k)
     f = ram.MipsIndex(d, dtype="f32")
