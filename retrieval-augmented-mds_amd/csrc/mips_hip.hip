@@ -496,38 +496,64 @@ const ScanInstance* v3_instances(int* n) {
     }
 }
 
-// scan_kernel_e8 (e4m3 documents x bf16 queries): instance by row pitch, query blocks per tile (1 / 2 / 4: tiles of 16 / 32 / 64
-// queries), ring depth, document cache policy.  Tiles of <= 32 queries run the pipelined one-barrier-per-block form where two
-// slot buffers fit next to the ring (everywhere but 32-query tiles at pitch 1024)
-inline bool e8_pipelined(int ld, int ncb) { return ncb == 1 || (ncb == 2 && ld <= 768); }
-inline int e8_stages(int ld, int ncb) { return ncb == 1 && ld <= 768 ? 4 : 3; }
+// scan_kernel_e8 (e4m3 documents x bf16 queries): instance by row pitch, configuration, document cache policy.
+// scan_kernel_e8 configurations: tiles of 16 / 32 / 64 queries (ncb = 1 / 2 / 4).  K parts (kw): 8 for the 16-query tile, 4 beyond
+// (half the partial sums through LDS: two slot buffers -- one barrier per block -- then fit for every tile but 64 queries at
+// pitch 1024); ring depth 4 where 160 KiB allow it.  old_rules: the first version's configurations (A/B library only).
+struct E8Config {
+    int ncb, stages, kw;
+    bool pipe;
+};
+inline E8Config e8_config(int ld, int64_t nq, bool old_rules) {
+    E8Config c;
+    if (old_rules) {
+        c.ncb = nq <= 16 ? 1 : (ld == 1024 || nq <= 32) ? 2 : 4;
+        c.kw = 8;
+        c.pipe = c.ncb == 1 || (c.ncb == 2 && ld <= 768);
+        c.stages = c.ncb == 1 && ld <= 768 ? 4 : 3;
+    } else {
+        c.ncb = nq <= 16 ? 1 : nq <= 32 ? 2 : 4;
+        c.kw = c.ncb == 1 ? 8 : 4;
+        c.pipe = c.ncb <= 2 || ld <= 768;
+        c.stages = c.ncb <= 2 && ld <= 768 ? 4 : 3;
+    }
+    return c;
+}
 template <int PUB>
-int launch_e8(mips_index* ix, const mips::ScanArgsE8& fa, int grid, int ncb, bool nt, hipStream_t st, int slot) {
-    const int stages = e8_stages(ix->ld, ncb);
-    const bool pipe = e8_pipelined(ix->ld, ncb);
+int launch_e8(mips_index* ix, const mips::ScanArgsE8& fa, int grid, const E8Config& c, bool nt, hipStream_t st, int slot) {
     // ring + slot buffer(s) + class words + dump + counters
-    const int lds = stages * mips::V3_DB * ix->ld + (pipe ? 2 : 1) * 8 * (2 * ncb) * 1024 + 2048 + 1024 + 64;
+    const int lds = c.stages * mips::V3_DB * ix->ld + (c.pipe ? 2 : 1) * c.kw * (2 * c.ncb) * 1024 + 2048 + 1024 + 64;
     auto go = [&](auto kern) -> int {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         if (ix->timing_armed) HIP_TRY(hipEventRecord(ix->ev0[slot], st));
         kern<<<grid, 512, lds, st>>>(fa);
         return MIPS_OK;
     };
-#define MIPS_E8_ROW(LDB, NCB, STG, PIPE) \
-    return nt ? go(mips::scan_kernel_e8<6, LDB, NCB, STG, true, PUB, PIPE>) : go(mips::scan_kernel_e8<6, LDB, NCB, STG, false, PUB, PIPE>)
-#define MIPS_E8_PITCH(LDB)                                              \
-    if (ix->ld == LDB) {                                                \
-        if (ncb == 1) { MIPS_E8_ROW(LDB, 1, (LDB <= 768 ? 4 : 3), true); } \
-        if (ncb == 2) { MIPS_E8_ROW(LDB, 2, 3, (LDB <= 768)); }         \
-        if constexpr (LDB <= 768) { MIPS_E8_ROW(LDB, 4, 3, false); }    \
+#define MIPS_E8_ROW(LDB, NCB, STG, PIPE, KW)                                               \
+    if (c.ncb == NCB && c.stages == STG && c.pipe == PIPE && c.kw == KW)                   \
+        return nt ? go(mips::scan_kernel_e8<6, LDB, NCB, STG, true, PUB, PIPE, KW>) : go(mips::scan_kernel_e8<6, LDB, NCB, STG, false, PUB, PIPE, KW>)
+#ifdef MIPS_EXPERIMENTAL
+#define MIPS_E8_OLD(LDB)                                                        \
+        MIPS_E8_ROW(LDB, 2, 3, (LDB <= 768), 8);                                \
+        if constexpr (LDB <= 768) { MIPS_E8_ROW(LDB, 4, 3, false, 8); }
+#else
+#define MIPS_E8_OLD(LDB)
+#endif
+#define MIPS_E8_PITCH(LDB)                                                      \
+    if (ix->ld == LDB) {                                                        \
+        MIPS_E8_ROW(LDB, 1, (LDB <= 768 ? 4 : 3), true, 8);                     \
+        MIPS_E8_ROW(LDB, 2, (LDB <= 768 ? 4 : 3), true, 4);                     \
+        MIPS_E8_ROW(LDB, 4, 3, (LDB <= 768), 4);                                \
+        MIPS_E8_OLD(LDB)                                                        \
     }
     MIPS_E8_PITCH(256)
     MIPS_E8_PITCH(512)
     MIPS_E8_PITCH(768)
     MIPS_E8_PITCH(1024)
 #undef MIPS_E8_PITCH
+#undef MIPS_E8_OLD
 #undef MIPS_E8_ROW
-    return fail(MIPS_E_UNSUPPORTED, "e4m3-documents index: no scan instance for row pitch %d with %d query blocks", ix->ld, ncb);
+    return fail(MIPS_E_UNSUPPORTED, "e4m3-documents index: no scan instance for row pitch %d with %d query blocks", ix->ld, c.ncb);
 }
 
 // tail_st: stream of the select + exact re-score launches (nullptr or == st: the scan's own stream)
@@ -566,7 +592,12 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // row pitch 1024) or 64; pools of 8 / 10 / 16 / 32 out of 8 sub-lists of 6 per (query, split), the class words vouching for
     // 8 PUB documents
     const bool e8 = ix->mixed;
-    const int e8_ncb = nq <= 16 ? 1 : (ix->ld == 1024 || nq <= 32) ? 2 : 4;
+#ifdef MIPS_EXPERIMENTAL
+    const E8Config e8c = e8_config(ix->ld, nq, ix->opt_sub == 71); // ("sub" = 71: the first version's configurations)
+#else
+    const E8Config e8c = e8_config(ix->ld, nq, false);
+#endif
+    const int e8_ncb = e8c.ncb;
     if (e8) {
         if (ix->ld % 256 != 0 || ix->ld > 1024) return fail(MIPS_E_UNSUPPORTED, "e4m3-documents index: d must pad to 256/512/768/1024");
         variant = 3;
@@ -715,10 +746,10 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
         fa.c = a;
         constexpr int PUB = KL <= 8 ? 1 : KL <= 16 ? 2 : 4;
         const bool nt = nqt == 1;
-        int rc2 = launch_e8<PUB>(ix, fa, grid, e8_ncb, nt, st, slot);
+        int rc2 = launch_e8<PUB>(ix, fa, grid, e8c, nt, st, slot);
         if (rc2) return rc2;
-        set_kernel_name(ix, "mips::scan_kernel_e8<6, %d, %d, %d, %s, %d, %s>", ix->ld, e8_ncb, e8_stages(ix->ld, e8_ncb), nt ? "true" : "false", PUB,
-                        e8_pipelined(ix->ld, e8_ncb) ? "true" : "false");
+        set_kernel_name(ix, "mips::scan_kernel_e8<6, %d, %d, %d, %s, %d, %s, %d>", ix->ld, e8c.ncb, e8c.stages, nt ? "true" : "false", PUB,
+                        e8c.pipe ? "true" : "false", e8c.kw);
     } else if (want_k3) {
         if constexpr (KL == 8 || KL == 16 || KL == 32) {
             constexpr int K3_PUB = KL / 8; // pool of 8 PUB candidates: every sub-list vouches for its PUB-th best

@@ -42,6 +42,7 @@ struct ScanArgsE8 {
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // 8 e4m3 bytes (two dwords, element j in byte j) -> 8 bf16 (exact)
 __device__ __forceinline__ bf16x8 e4m3x8_to_bf16x8(unsigned lo, unsigned hi) {
@@ -64,13 +65,19 @@ __device__ __forceinline__ bf16x8 e4m3x8_to_bf16x8(unsigned lo, unsigned hi) {
 
 // KL: entries per sub-list; LDB: row pitch in bytes = padded K (256 .. 1024); NCB: 16-query column blocks per tile (1, 2 or 4);
 // STAGES: ring depth; NT_DOCS: non-temporal document DMA (one query tile: every block has a single reader); PIPE: see above
-template <int KL, int LDB, int NCB, int STAGES, bool NT_DOCS, int PUB = 1, bool PIPE = false>
+// KW: K parts.  8: wave w multiplies K part w of BOTH 16-document halves (2 NCB partial tiles per wave).  4: wave w multiplies K
+// part w & 3 of document half w >> 2 (NCB partial tiles per wave): the same fragments converted and the same MFMAs per wave, but
+// half the partial sums through LDS and half the slot bytes -- which is what lets tiles of 64 queries keep two slot buffers
+// (PIPE) beside a 3-stage ring.
+template <int KL, int LDB, int NCB, int STAGES, bool NT_DOCS, int PUB = 1, bool PIPE = false, int KW = 8>
 __global__ __launch_bounds__(512, 2) void scan_kernel_e8(ScanArgsE8 pa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const ScanArgs& p = pa.c;
     constexpr int WAVES = 8;
     constexpr int TN = 16 * NCB;                    // queries per workgroup
-    constexpr int KS = LDB / 256;                   // k32-steps per wave (K / 8 columns)
+    static_assert(KW == 8 || KW == 4, "K parts");
+    constexpr int KS = LDB / (32 * KW);             // k32-steps per wave (K / KW columns)
+    constexpr int HPW = KW == 8 ? 2 : 1;            // 16-document halves per wave
     constexpr int STAGE_BYTES = V3_DB * LDB;        // 32 rows x K bytes
     constexpr int PIECES = STAGE_BYTES / 1024;
     constexpr int PPW = PIECES / WAVES;
@@ -80,10 +87,10 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_e8(ScanArgsE8 pa) {
     static_assert(TILES <= WAVES, "one reducing wave per accumulator tile");
     static_assert(KL <= 8 && STAGES >= 3 && PUB >= 1 && PUB <= KL, "");
 
-    // ---- LDS map: ring | exchange slots [wave][tile][64 lanes][4 floats] | class words of the tile's queries (+ dump) | counters
+    // ---- LDS map: ring | exchange slots [K part][tile][64 lanes][4 floats] | class words of the tile's queries (+ dump) | counters
     constexpr unsigned XCH_AREA = STAGES * STAGE_BYTES;
-    constexpr unsigned XCH_WAVE = TILES * 1024u;
-    constexpr unsigned XCH_BUF = WAVES * XCH_WAVE;               // one buffer of slots; PIPE keeps two
+    constexpr unsigned XCH_WAVE = TILES * 1024u;                 // one K part's partial tiles
+    constexpr unsigned XCH_BUF = KW * XCH_WAVE;                  // one buffer of slots; PIPE keeps two
     constexpr unsigned THR_AREA = XCH_AREA + (PIPE ? 2u : 1u) * XCH_BUF; // 16 NCB queries x 32 B (<= 2 KiB)
     constexpr unsigned THR_BYTES = TN * 32u;
     constexpr unsigned DUMP_AREA = THR_AREA + 2048u;             // 1 KiB: where the dummy refresh "lands"
@@ -108,11 +115,13 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_e8(ScanArgsE8 pa) {
     if (b1 > p.ntiles) b1 = p.ntiles;
     const int nb = b1 > b0 ? b1 - b0 : 0;
 
-    // ---- stationary query fragments of this wave's K slice: lane holds Q[q0 + 16 n + c][32 (KS wave + j) + 8 g .. +8)
+    const int kp = KW == 8 ? wave : (wave & 3);     // this wave's K part ...
+    const int dh = KW == 8 ? 0 : (wave >> 2);       // ... and (KW = 4) its document half
+    // ---- stationary query fragments of this wave's K slice: lane holds Q[q0 + 16 n + c][32 (KS kp + j) + 8 g .. +8)
     bf16x8 bq[NCB][KS];
 #pragma unroll
     for (int n = 0; n < NCB; ++n) {
-        const uint16_t* qrow = p.qbuf + ((int64_t)qt * TN + n * 16 + c) * p.ld + 32 * KS * wave + 8 * g;
+        const uint16_t* qrow = p.qbuf + ((int64_t)qt * TN + n * 16 + c) * p.ld + 32 * KS * kp + 8 * g;
 #pragma unroll
         for (int j = 0; j < KS; ++j) bq[n][j] = *reinterpret_cast<const bf16x8*>(qrow + 32 * j);
     }
@@ -203,48 +212,59 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_e8(ScanArgsE8 pa) {
     // this wave's K slice of the block in ring stage `stg`: convert + multiply, partial sums -> its slot of buffer `buf`
     auto multiply = [&](int stg, unsigned buf) {
         const unsigned char* sa = smem + stg * STAGE_BYTES;
-        f32x4 acc[2][NCB];
+        f32x4 acc[HPW][NCB];
 #pragma unroll
-        for (int half = 0; half < 2; ++half)
+        for (int half = 0; half < HPW; ++half)
 #pragma unroll
             for (int n = 0; n < NCB; ++n) acc[half][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         const unsigned ln = lane_id_here();
         const unsigned cc = ln & 15u, gg = ln >> 4;
-        const unsigned rowoff = cc * 128u + 8u * (gg & 1u);
+        const unsigned rowoff = cc * 128u + 8u * (gg & 1u) + (unsigned)dh * 2048u; // (rows 16 dh + c: 16 rows x 128 B per slab half)
         const unsigned swz = (cc >> 1) & 7u;
+        // all KS fragment reads of this wave are issued up front (2 HPW registers each) and waited for one k-step at a time: with a
+        // read + lgkmcnt(0) per step the LDS round trip (~100 cycles) was exposed KS times per block
+        // (inline asm: behind an ordinary load of an LDS-DMA destination hipcc first drains vmcnt(0) -- the whole ring)
+        u32x2 raw[KS][2]; // (a native vector type: the "+v" ties of the waits below are not honoured for HIP's uint2 struct)
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
-            const int sg = KS * wave + j;              // global k32-step (wave-uniform)
+            const int sg = KS * kp + j;                // global k32-step (wave-uniform)
             const unsigned chunk = 2u * (unsigned)(sg & 3) + (gg >> 1);
             const unsigned off = (unsigned)(sg >> 2) * 4096u + rowoff + ((chunk ^ swz) << 4);
-            // (inline asm: behind an ordinary load of an LDS-DMA destination hipcc first drains vmcnt(0) -- the whole ring)
-            uint2 raw[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+            raw[j][0] = raw[j][1] = u32x2{0u, 0u};
 #if defined(__HIP_DEVICE_COMPILE__)
-            {
-                const unsigned a0 = (unsigned)(size_t)(lds_void*)sa + off;
-                asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:2048\n\ts_waitcnt lgkmcnt(0)" : "=&v"(raw[0]), "=&v"(raw[1]) : "v"(a0) : "memory");
-            }
+            const unsigned a0 = (unsigned)(size_t)(lds_void*)sa + off;
+            if (HPW == 2) asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:2048" : "=&v"(raw[j][0]), "=&v"(raw[j][1]) : "v"(a0) : "memory");
+            else asm volatile("ds_read_b64 %0, %1" : "=&v"(raw[j][0]) : "v"(a0) : "memory");
+#endif
+        }
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            // the reads of steps 0 .. j have returned once at most HPW (KS - 1 - j) are outstanding (LDS returns in order)
+            if (HPW == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(raw[j][0]), "+v"(raw[j][1]) : "n"(2 * (KS - 1 - j)) : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(raw[j][0]) : "n"(KS - 1 - j) : "memory");
 #endif
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const bf16x8 af = e4m3x8_to_bf16x8(raw[half].x, raw[half].y);
+            for (int half = 0; half < HPW; ++half) {
+                const bf16x8 af = e4m3x8_to_bf16x8(raw[j][half][0], raw[j][half][1]);
 #pragma unroll
                 for (int n = 0; n < NCB; ++n) acc[half][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bq[n][j], acc[half][n], 0, 0, 0);
             }
         }
-        unsigned char* slot = smem + XCH_AREA + buf * XCH_BUF + wave * XCH_WAVE + ln * 16u;
+        // partial tile (document half h, query block n) of K part kp: slot [kp][h NCB + n]
+        unsigned char* slot = smem + XCH_AREA + buf * XCH_BUF + (unsigned)kp * XCH_WAVE + ln * 16u;
 #pragma unroll
-        for (int half = 0; half < 2; ++half)
+        for (int half = 0; half < HPW; ++half)
 #pragma unroll
-            for (int n = 0; n < NCB; ++n) *reinterpret_cast<f32x4*>(slot + (half * NCB + n) * 1024) = acc[half][n];
+            for (int n = 0; n < NCB; ++n) *reinterpret_cast<f32x4*>(slot + ((HPW == 2 ? half : dh) * NCB + n) * 1024) = acc[half][n];
     };
-    // (reducing waves) tile `wave` of block `blk`: the 8 slots of buffer `buf` summed in slot order, then the top-K epilogue
+    // (reducing waves) tile `wave` of block `blk`: the KW slots of buffer `buf` summed in slot order, then the top-K epilogue
     auto reduce = [&](int blk, unsigned buf, bool refresh) {
         const unsigned ln = lane_id_here();
         const unsigned char* src = smem + XCH_AREA + buf * XCH_BUF + (unsigned)wave * 1024u + ln * 16u;
         f32x4 sum = *reinterpret_cast<const f32x4*>(src);
 #pragma unroll
-        for (int w = 1; w < WAVES; ++w) sum = sum + *reinterpret_cast<const f32x4*>(src + w * XCH_WAVE);
+        for (int w = 1; w < KW; ++w) sum = sum + *reinterpret_cast<const f32x4*>(src + w * XCH_WAVE);
         if (refresh) { // minimum of the 8 class words of query 16 tn + c (what an earlier refresh brought, or 0)
             const unsigned a0 = (unsigned)(size_t)(lds_void*)smem + THR_AREA + ((unsigned)tn * 16u + (ln & 15u)) * 32u;
             u32x4 w0 = {0u, 0u, 0u, 0u}, w1 = w0;
