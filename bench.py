@@ -563,7 +563,7 @@ def main():
             "margin_check": {"flagged_queries_last_step": margin["flagged"], "settled_exactly": margin["rescanned"],
                              "unresolved": margin["unresolved"], "of": nq,
                              "mode": "certified on the stream: every search settles the queries it flags exactly (brute force on the canonical "
-                                     "scores, one pass over the index per 8 flagged queries), without synchronising; a run that leaves a "
+                                     "scores behind an MFMA pre-filter, one pass over the index per 16 flagged queries), without synchronising; a run that leaves a "
                                      "query unresolved prints no value",
                              "bound": "exact k-th score within d*2^-23*|q|*max|x| of the best MFMA score outside the candidate pool"},
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_torch": cpu_t, "parity_vs_cpu_sample": parity,

@@ -298,9 +298,10 @@ int mips_index_check_error(mips_index_t* index, int synchronize, void* hip_strea
  * bound, documents dropped from a full running list) and FLAGS the query when B + e >= tk, e = d 2^-23 |q| max|x|
  * (a rigorous bound for fp32 accumulation of the exact bf16 / e4m3 products).  "margin_check" (mips_index_set_param):
  *   0  off (an fp32-exact index then always runs the three-segment scan);
- *   1  (default) CERTIFY: flagged queries are settled EXACTLY -- one pass over the stored rows per 8 flagged queries computes
- *      the canonical scores by brute force (csrc/resolve_kernels.hpp) and the rows reaching the current k-th result are
- *      ranked over it.  Searches into HOST buffers synchronise anyway: they read the flag count first and skip the pass
+ *   1  (default) CERTIFY: flagged queries are settled EXACTLY -- one pass over the stored rows per 16 flagged queries (8 on the
+ *      e4m3 indexes) computes canonical scores by brute force (csrc/resolve_kernels.hpp: of every row whose MFMA score comes
+ *      within the error bound of the current k-th key; on the e4m3 indexes, and with "resolve" = 2, of every row) and the rows
+ *      reaching the current k-th result are ranked over it.  Searches into HOST buffers synchronise anyway: they read the flag count first and skip the pass
  *      when it is 0.  Searches with DEVICE outputs never synchronise: flag list and count live on the device, the passes
  *      are enqueued behind the first scan and leave at once when nothing is flagged (a few microseconds), graph-capturable;
  *      split-tail searches (mips_search_split) run them on their tail stream.  The one-launch kernel (mips_search_fused,

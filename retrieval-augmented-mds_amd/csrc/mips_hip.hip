@@ -161,7 +161,7 @@ struct mips_index {
     // synchronise anyway) unless the check is off.
     int opt_margin = 1;
     Buffer mbnd, mflag, qbuf2, qf32b, tmp_s, tmp_i, ids, qhi, qerr2, keyk, qqv, hit_d, hit_i, hit_n, qnorm;
-    int opt_resolve = 1; // flagged queries: 1 = exact brute-force resolution (resolve_kernels.hpp), 0 = re-scan with the widest lists
+    int opt_resolve = 1; // flagged queries: 1 = exact brute-force resolution (resolve_kernels.hpp; 2 = its plain form, no MFMA pre-filter), 0 = re-scan with the widest lists
     int resolve_budget = 0; // "resolve_budget" > 0: flagged queries a search resolves at most (0 = RESOLVE_MAX); a search that flags
                             // more keeps its first results (counted unresolved) -- or, if its first scan was an optimistic one,
                             // goes through the stream-ordered re-scan with true K' = 32 lists
@@ -1290,16 +1290,40 @@ int resolve_flagged(mips_index* ix, int64_t nq, int k, float* d_s, int64_t* d_i,
     a.unresolved = unres;
     a.ignore = ignore;
     a.k_out = ignore ? k_out : 0;
-    const int lds = mips::RESOLVE_QB * a.ld * (int)sizeof(double) + mips::RESOLVE_WAVES * 64 * 9 * 16;
+    int lds = mips::RESOLVE_QB * a.ld * (int)sizeof(double) + mips::RESOLVE_WAVES * 64 * 9 * 16;
     const int rows_per_wg = 64 * mips::RESOLVE_WAVES;
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (ix->ntotal + rows_per_wg - 1) / rows_per_wg));
+    int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (ix->ntotal + rows_per_wg - 1) / rows_per_wg));
     const bool l2 = ix->call_metric == MIPS_METRIC_L2;
     auto go = [&](auto kern) -> int {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         kern<<<grid, 64 * mips::RESOLVE_WAVES, lds, st>>>(a);
         return MIPS_OK;
     };
-    if (f32x) rc = l2 ? go(mips::exact_filter_kernel<mips::ElemF32, true>) : go(mips::exact_filter_kernel<mips::ElemF32, false>);
+    // bf16-stored rows and the fp32-exact index: the same pass behind an MFMA pre-filter (16 flagged queries per pass, canonical
+    // evaluation of the few rows whose approximate score comes within the error bound of the k-th key; "resolve" = 2 keeps the
+    // plain form -- tests compare the two)
+    const int ffld = f32x ? ix->hp : ix->ld;
+    const bool mfma_filter = ix->opt_resolve == 1 && (f32x ? (ix->hp > 0 && ix->rows_hi != nullptr) : (ix->esize == 2 && !ix->mixed)) &&
+                             ffld % 64 == 0 && ffld <= 1024 && a.ld <= 1024;
+    if (mfma_filter) {
+        if (f32x) {
+            rc = ensure_hi(ix, st);
+            if (rc) return rc;
+        }
+        rc = ensure_xmax2(ix, st);
+        if (rc) return rc;
+        a.frows = f32x ? (const uint16_t*)ix->rows_hi : (const uint16_t*)ix->rows;
+        a.fld = ffld;
+        a.xmax2 = ix->xmax2_dev;
+        a.dres2 = ix->dres2_dev;
+        a.err_c = (double)ix->d * 1.1920928955078125e-07 * (f32x ? 1.01 : 1.0);
+        // query image (row pitch + 16 B) + the waves' product staging + statistics / thresholds / keys / ids
+        lds = ((mips::RESOLVE_QM * (ffld * 2 + 16) + 15) & ~15) + mips::RESOLVE_WAVES * 64 * 8 * 8 + 2 * mips::RESOLVE_QM * 8 + 3 * mips::RESOLVE_QM * 4;
+        const int64_t tiles = (ix->ntotal + 15) / 16;
+        grid = (int)std::max<int64_t>(1, std::min<int64_t>(512, (tiles + mips::RESOLVE_WAVES - 1) / mips::RESOLVE_WAVES));
+        if (f32x) rc = l2 ? go(mips::exact_filter_mfma_kernel<true, true>) : go(mips::exact_filter_mfma_kernel<false, true>);
+        else rc = l2 ? go(mips::exact_filter_mfma_kernel<true, false>) : go(mips::exact_filter_mfma_kernel<false, false>);
+    } else if (f32x) rc = l2 ? go(mips::exact_filter_kernel<mips::ElemF32, true>) : go(mips::exact_filter_kernel<mips::ElemF32, false>);
     else if (ix->mixed) rc = l2 ? go(mips::exact_filter_kernel<mips::ElemF8, true, mips::ElemBF16>) : go(mips::exact_filter_kernel<mips::ElemF8, false, mips::ElemBF16>);
     else if (ix->esize == 1) rc = l2 ? go(mips::exact_filter_kernel<mips::ElemF8, true>) : go(mips::exact_filter_kernel<mips::ElemF8, false>);
     else rc = l2 ? go(mips::exact_filter_kernel<mips::ElemBF16, true>) : go(mips::exact_filter_kernel<mips::ElemBF16, false>);
@@ -2259,7 +2283,7 @@ int mips_index_set_param(mips_index_t* ix, const char* name, int64_t value) {
 #endif
     }
     else if (n == "tiny") ix->opt_tiny = value == 2 ? 2 : value != 0 ? 1 : 0; // 2: one launch, fall-back paths forced (tests)
-    else if (n == "resolve") ix->opt_resolve = value != 0 ? 1 : 0;
+    else if (n == "resolve") ix->opt_resolve = value < 0 ? 0 : value > 2 ? 2 : (int)value; // 2: exact pass without the MFMA pre-filter
     else if (n == "f32_fast" || n == "optimistic") { // (one switch: two-stage fp32 search and optimistic pools, include/mips_hip.h)
         if (value < 0 || value > 2) return fail(MIPS_E_INVALID, "mips_index_set_param: f32_fast / optimistic must be 0, 1 or 2");
         ix->opt_f32_fast = (int)value;

@@ -2003,6 +2003,46 @@ def test_hook_on_clustered_fp32_rows_returns_the_brute_force_neighbours(tmp_path
         assert np.array_equal(i2.cpu().numpy(), np.delete(ei5, 2, axis=1)) and np.array_equal(s2.cpu().numpy(), np.delete(es5, 2, axis=1))
 
 
+@pytest.mark.parametrize("dtype,d,metric", [("bf16", 768, 0), ("bf16", 1000, 1), ("bf16", 320, 0), ("f32", 768, 0), ("f32", 1000, 0), ("f32", 300, 1)])
+def test_exact_pass_mfma_prefilter_equals_the_plain_pass(dtype, d, metric):
+    """The exact pass of flagged queries behind its MFMA pre-filter ("resolve" = 1, the default: 16 flagged queries per pass, only
+    rows whose approximate score comes within the error bound of the k-th key are evaluated canonically) against the plain pass
+    ("resolve" = 2: the canonical fp64 score of EVERY row for 8 queries per pass): the same results, the same statistics, and the
+    brute-force oracle's rows -- on clusters of near-identical rows (dozens of flagged queries, exact ties among the hits),
+    with 40 flagged queries (three passes of the filtered form) and with one."""
+    rng = np.random.default_rng(d + metric)
+    nc, per = 160, 45
+    c = rng.standard_normal((nc, d)).astype(np.float32)
+    x = (np.repeat(c, per, axis=0) * (1.0 + 1e-4 * rng.standard_normal((nc * per, 1)))).astype(np.float32)
+    x += (1e-4 * rng.standard_normal(x.shape)).astype(np.float32)
+    x[7 * per + 3] = x[7 * per + 1]                                  # two exact duplicates inside a cluster: a tie among the hits
+    x = np.concatenate([x, rng.standard_normal((20011, d)).astype(np.float32)])     # a ragged tail of ordinary rows
+    if dtype == "bf16":
+        x = synth.round_to_bf16(x)
+    k = 5
+    for nq in (40, 1):
+        q = (c[rng.integers(0, nc, nq)] + 0.01 * rng.standard_normal((nq, d))).astype(np.float32)
+        if nq == 40:
+            q[0] = c[7]
+        if dtype == "bf16":
+            q = synth.round_to_bf16(q)
+        es, ei = orc.search_exact_bruteforce(q, x, k, metric=metric)          # (tie-safe enumeration)
+        ix = ram.MipsIndex(d, metric=metric, dtype=dtype)
+        ix.add(x)
+        out = {}
+        for mode in (2, 1):
+            ix.set_param("resolve", mode)
+            s, i = ix.search(torch.from_numpy(q).cuda(), k)
+            out[mode] = (s.cpu().numpy(), i.cpu().numpy(), ix.margin_stats())
+            hs, hi = ix.search(q, k)                                 # host buffers: the synchronising form of the same pass
+            assert np.array_equal(hi, out[mode][1]) and np.array_equal(hs, out[mode][0]), (mode, nq)
+        assert out[1][2] == out[2][2] and out[1][2]["unresolved"] == 0, (out[1][2], out[2][2])
+        assert nq == 1 or out[1][2]["flagged"] > 0, (nq, out[1][2])   # (the single query runs the one-launch kernel: flagged or not, same rows)
+        assert np.array_equal(out[1][1], out[2][1]) and np.array_equal(out[1][0], out[2][0])
+        assert np.array_equal(out[1][0], es) and np.array_equal(out[1][1], ei)   # (equal scores in the oracle's order: idx asc)
+        ix.check()
+
+
 # ------------------------------------------------------------------ round 3: the certification budget and what lies beyond it
 def test_resolve_budget_exactly_met_and_exceeded():
     """"resolve_budget": flagged queries ONE search settles at most (default 1024).  A device-output search that flags exactly
