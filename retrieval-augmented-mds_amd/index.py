@@ -272,9 +272,10 @@ class MipsIndex:
 
     def margin_stats(self, synchronize: bool = True) -> dict:
         """Margin check of the LAST search (include/mips_hip.h, mips_index_margin_stats): {"flagged": queries whose
-        candidate pool was not provably wide enough, "rescanned": of those re-scanned with the widest lists,
-        "unresolved": still flagged}.  set_param("margin_check", 0 | 1 | 2 | 3) selects off / count only (default for
-        device tensors) / certify (synchronise + re-scan; NumPy searches always do)."""
+        candidate pool was not provably wide enough, "rescanned": of those settled (exactly, by the brute-force pass, or by the
+        re-scan with the widest lists), "unresolved": left with their first result}.  set_param("margin_check", m): 0 off,
+        1 (default) certify -- NumPy searches with a synchronisation, CUDA searches stream-ordered, without one --,
+        2 certify and synchronise, 3 stream-ordered explicitly, 4 count only."""
         f, r, u = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         _lib.check(self._lib.mips_index_margin_stats(self._h, ctypes.byref(f), ctypes.byref(r), ctypes.byref(u),
                                                      int(bool(synchronize)), _stream_handle(self.device)),

@@ -186,9 +186,9 @@ class ShardedMipsIndex:
         return self
 
     def set_param(self, name: str, value: int) -> None:
-        """Knob of the LOCAL scan (MipsIndex.set_param) -- every rank sets its own.  `set_param("margin_check", 3)` makes the
-        local device-output searches certify without synchronising (stream-ordered re-scan of the queries they flag), which
-        also opens the optimistic / two-stage paths (8 <= k <= 13, fp32-exact shards) to the sharded search."""
+        """Knob of the LOCAL scan (MipsIndex.set_param) -- every rank sets its own.  The default margin mode already certifies
+        the local device-output searches without synchronising (the exact pass of the queries they flag is enqueued behind the
+        scan), which keeps the optimistic / two-stage paths (8 <= k <= 29, fp32-exact shards) open to the sharded search."""
         self.local.set_param(name, value)
 
     def margin_stats(self, synchronize: bool = True, reduce: bool = True) -> dict:
