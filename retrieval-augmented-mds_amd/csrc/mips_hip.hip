@@ -689,7 +689,13 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
 #else
     const bool short_lists = false;
 #endif
-    const int list_len = want_k3 ? K3_KLL : (want_v4 || want_v5 || want_ks || want_f8x || short_lists || e8) ? V4_KLL : KL; // entries per running list
+    int list_len = want_k3 ? K3_KLL : (want_v4 || want_v5 || want_ks || want_f8x || short_lists || e8) ? V4_KLL : KL; // entries per running list
+#ifdef MIPS_EXPERIMENTAL
+    // shorter sub-lists buy registers for a deeper A-fragment prefetch in scan_kernel_v4 ("sub" = 55 / 56 / 57: lists of 5 at depth 2,
+    // lists of 5 at depth 3, lists of 4 at depth 3; same results -- what a shorter list drops the margin check prices)
+    if (want_v4 && ix->ld == 768 && (ix->opt_sub == 55 || ix->opt_sub == 56)) list_len = 5;
+    if (want_v4 && ix->ld == 768 && ix->opt_sub == 57) list_len = 4;
+#endif
     const size_t ncand = (size_t)nsplit * lists * list_len;
     int rc = ix->part_s.ensure((size_t)nq_pad * ncand * sizeof(float));
     if (rc) return rc;
@@ -827,6 +833,9 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             else if (ix->ld == 768 && ix->opt_sub == 46) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 6>); // timing only: no document DMA
             else if (ix->ld == 768 && ix->opt_sub == 47) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 7>); // timing only: no block barrier wait
             else if (ix->ld == 768 && ix->opt_sub == 48) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 8>); // timing only: no DMA, no epilogue
+            else if (ix->ld == 768 && ix->opt_sub == 55) rc2 = go4(mips::scan_kernel_v4<5, 24, 2, 0>);
+            else if (ix->ld == 768 && ix->opt_sub == 56) rc2 = go4(mips::scan_kernel_v4<5, 24, 3, 0>);
+            else if (ix->ld == 768 && ix->opt_sub == 57) rc2 = go4(mips::scan_kernel_v4<4, 24, 3, 0>);
             else if (ix->ld == 768 && ix->opt_sub == 49) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 9>); // SIMD partners issue their DMA pieces half a period apart
             else if (ix->ld == 768 && ix->opt_sub == 50) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 10>); // second wave of a SIMD starts 64 cycles late
             else if (ix->ld == 768 && ix->opt_sub == 52) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 11>); // ... 128
