@@ -2131,6 +2131,41 @@ def test_optimistic_first_scan_over_the_budget_is_rescanned_not_kept():
     assert ok[np.setdiff1d(np.arange(300), stars)].all()
 
 
+def test_pitch_1024_pools_over_the_budget_fall_back_to_true_lists():
+    """Row pitch 1024, bf16, k = 10, more than 256 queries: pools of 32 out of scan_kernel_k3's sub-lists (an optimistic first
+    scan).  With clusters of 45 near-identical rows and a budget of 4 the search flags more than it may settle exactly: the
+    stream-ordered fall-back (true K' = 32 lists on the 4-wave kernel) runs, and every query it certifies -- all the ordinary
+    ones -- carries the oracle's rows; within the budget the exact pass settles all of them."""
+    rng = np.random.default_rng(1024)
+    d, nc, per, k = 1024, 30, 45, 10
+    c = rng.standard_normal((nc, d)).astype(np.float32)
+    x = (np.repeat(c, per, axis=0) * (1.0 + 1e-4 * rng.standard_normal((nc * per, 1)))).astype(np.float32)   # (mostly equal after bf16 rounding)
+    x = synth.round_to_bf16(np.concatenate([x, rng.standard_normal((30011, d)).astype(np.float32)]))
+    nq = 300
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    hard = np.arange(0, nq, 11)
+    q[hard] = c[rng.integers(0, nc, len(hard))] + 0.01 * rng.standard_normal((len(hard), d)).astype(np.float32)
+    q = synth.round_to_bf16(q)
+    es, ei = orc.search_exact(q, x, k)
+    es[hard], ei[hard] = orc.search_exact_bruteforce(q[hard], x, k)       # (tie-safe enumeration where ties can be)
+    ix = _index(x)
+    qd = torch.from_numpy(q).cuda()
+    s, i = ix.search(qd, k)                                               # default budget: everything flagged is settled exactly
+    assert ix.last_kernel.startswith("mips::scan_kernel_k3<4, 32, 2, 0, 4>"), ix.last_kernel
+    st = ix.margin_stats()
+    assert st["flagged"] > 4 and st["unresolved"] == 0, st
+    assert np.array_equal(i.cpu().numpy(), ei) and np.array_equal(s.cpu().numpy(), es)
+    ix.set_param("resolve_budget", 4)
+    s, i = ix.search(qd, k)
+    st4 = ix.margin_stats()
+    assert st4["flagged"] == st["flagged"] and st4["rescanned"] == st4["flagged"], (st, st4)
+    ok = (i.cpu().numpy() == ei).all(axis=1) & (s.cpu().numpy() == es).all(axis=1)
+    assert ok.sum() >= nq - st4["unresolved"], (int(ok.sum()), st4)
+    assert ok[np.setdiff1d(np.arange(nq), hard)].all()
+    assert not (i.cpu().numpy() == ram.IDX_POISON).any()
+    ix.check()
+
+
 def test_bench_two_rank_line_carries_the_sharded_regimes():
     """`python bench.py --gpus 2 --backend gloo --rows 65536` (both ranks on this one GPU, host-staged collective): the N > 1
     line keeps the headline contract AND carries `regimes` -- the row-sharded BASELINE config 3 / 5 forms (here at reduced size)
