@@ -17,8 +17,10 @@ case = 0
 while time.time() < t_end:
     case += 1
     dtype = str(rng.choice(["bf16", "bf16", "f32"]))
-    d = int(rng.choice([384, 512, 640, 768, 768, 704, 304]))
+    d = int(rng.choice([384, 512, 640, 768, 768, 704, 304, 1024, 1000]))
     n = int(rng.integers(200000, 1 << 20)) if dtype == "bf16" else int(rng.integers(100000, 400000))
+    if dtype == "bf16" and d > 768 and rng.random() < 0.4:
+        n = int(rng.integers(1 << 21, (1 << 21) + 300000))           # row pitch 1024, large index: the pool of 16 for k <= 5
     nq = int(rng.choice([300, 1000, 2048, 4096]))
     k = int(rng.choice([5, 6, 8, 10, 13])) if dtype == "bf16" else int(rng.choice([5, 6, 10]))
     ix = ram.MipsIndex(d, dtype=dtype)
@@ -33,7 +35,13 @@ while time.time() < t_end:
         q = (q.float() * 1.2345).contiguous()
     ix.set_param("margin_check", 2)
     outs = []
-    paths = [("optimistic", 0), ("optimistic", 1)] if (k >= 8 or dtype == "f32") else [("variant", 3), ("variant", 4), ("variant", 0)]
+    if k >= 8 or dtype == "f32":
+        paths = [("optimistic", 0), ("optimistic", 1)]
+    elif d > 768:                                                   # pitch 1024: 4-wave kernel, K-split pairs, automatic (+ its pool of 16)
+        paths = [("variant", 3), ("variant", 7), ("variant", 0), ("optimistic", 0)]
+    else:
+        paths = [("variant", 3), ("variant", 4), ("variant", 0)]
+    paths.append(("resolve", 2))                                    # the plain exact pass instead of the MFMA-filtered one
     names = []
     for name, v in paths:
         ix.set_param(name, v)
@@ -41,7 +49,7 @@ while time.time() < t_end:
         st = ix.margin_stats()
         outs.append((s, i))
         names.append(f"{name}={v}:{ix.last_kernel}:{st['flagged']}/{st['unresolved']}")
-        ix.set_param(name, 1 if name == "optimistic" else 0)
+        ix.set_param(name, 1 if name in ("optimistic", "resolve") else 0)
     ok = all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
     print(f"case {case}: dtype={dtype} n={n} nq={nq} d={d} k={k} {' | '.join(names)} -> {'ok' if ok else 'MISMATCH'}", flush=True)
     if not ok:
