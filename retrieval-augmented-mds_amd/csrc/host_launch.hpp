@@ -197,7 +197,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // scan_kernel_k3 (round 3): the wave pairs of scan_kernel_ks with 48 queries each -- 192 stationary queries per CU, a third
     // less L2 -> LDS fill per flop, which is what bounds pitch 1024.  Default there once several 192-query tiles share the
     // document stream (the MFMA-bound regime); smaller searches keep the 128-query configuration ("variant" = 7 / 3 force one)
-    const bool want_k3 = k3_opt || (ks_shape && (ix->opt_sub == 0 || (ix->opt_sub >= 61 && ix->opt_sub <= 68)) && (ix->opt_variant == 7 || (ix->opt_variant == 0 && nq > 256)));
+    const bool want_k3 = k3_opt || (ks_shape && (ix->opt_sub == 0 || (ix->opt_sub >= 61 && ix->opt_sub <= 69)) && (ix->opt_variant == 7 || (ix->opt_variant == 0 && nq > 256)));
     constexpr int K3_KLL = 4; // entries per sub-list (the third accumulator set is paid for with shorter lists)
     // (a variant on 16-document stages -- 4-stage ring, three blocks in flight, one barrier per 16 documents -- was built and
     // measured 18 % SLOWER, 34.8 vs 29.5 ms at 2^22 x 1024: profiles/r3_pitch1024/README.md; what parks the waves is the barrier
@@ -342,6 +342,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             else if (ix->opt_sub == 66) rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 6>);
             else if (ix->opt_sub == 67) rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 7>); // + L2 prefetch three blocks ahead
             else if (ix->opt_sub == 68) rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 8>); // ... six blocks ahead
+            else if (ix->opt_sub == 69) rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 9>); // ... three ahead, by one workgroup per document stream only
             else
 #endif
             rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 0, K3_PUB>);

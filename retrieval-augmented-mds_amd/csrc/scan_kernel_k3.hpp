@@ -59,6 +59,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
     const int qt = (xcd % p.qgroups) + p.qgroups * (j0 % p.qt_per_group);
     const int split = (xcd / p.qgroups) * p.splits_per_group + j0 / p.qt_per_group;
     if (qt >= p.nqt) return;
+    const bool pf_leader = (j0 % p.qt_per_group) == 0;
     if (p.spin_limit < 0 && tid == 0) *p.err = 1u; // test-only: force the scan-error path (include/mips_hip.h, "spin_limit")
     const bool idle_pair = (qt * TN + pair * 16 * NCB) >= p.nq; // all 48 queries of the pair are padding (scan_kernel_v3.hpp)
 
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
     constexpr unsigned XCH_WAVE = NCB * 1024u;
     constexpr unsigned CNT_AREA = XCH_AREA + WAVES * XCH_WAVE;
     constexpr unsigned PF_AREA = CNT_AREA + 64;     // 256 B nobody reads: where the L2 prefetch of a later block lands
-    constexpr bool PREFETCH = TIMING_MODE == 7 || TIMING_MODE == 8;
+    constexpr bool PREFETCH = TIMING_MODE == 7 || TIMING_MODE == 8 || TIMING_MODE == 9;
     static_assert(PF_AREA + 256 <= 160 * 1024, "LDS budget");
     // p.gthr = [query tile][pair][48 queries][8 words]: both waves of a pair publish into the same 1.5 KiB
     const __amdgpu_buffer_rsrc_t thr_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -167,7 +168,10 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
     auto prefetch_block = [&](const unsigned char* blk_base) {
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void*)blk_base, 0, (int)(V3_DB * row_bytes), 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + PF_AREA), 4, lane_id_here() * 128u, wave * 8192, 0, 0);
+        // TIMING_MODE 9: only ONE of the workgroups that share a document stream (the first query tile of its XCD group) touches
+        // memory; the others issue the same operation out of range (no access, zeros into the dummy area; uniform vmcnt arithmetic)
+        const unsigned voff = (TIMING_MODE != 9 || pf_leader) ? lane_id_here() * 128u : (0x40000000u | (lane_id_here() * 4u));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + PF_AREA), 4, voff, wave * 8192, 0, 0);
     };
     auto poll = [&](unsigned addr, unsigned need) {
         for (int spin = 0;; ++spin) {
