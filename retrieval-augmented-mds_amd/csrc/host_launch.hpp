@@ -197,7 +197,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // scan_kernel_k3 (round 3): the wave pairs of scan_kernel_ks with 48 queries each -- 192 stationary queries per CU, a third
     // less L2 -> LDS fill per flop, which is what bounds pitch 1024.  Default there once several 192-query tiles share the
     // document stream (the MFMA-bound regime); smaller searches keep the 128-query configuration ("variant" = 7 / 3 force one)
-    const bool want_k3 = k3_opt || (ks_shape && (ix->opt_sub == 0 || (ix->opt_sub >= 61 && ix->opt_sub <= 69)) && (ix->opt_variant == 7 || (ix->opt_variant == 0 && nq > 256)));
+    const bool want_k3 = k3_opt || (ks_shape && (ix->opt_sub == 0 || (ix->opt_sub >= 61 && ix->opt_sub <= 74)) && (ix->opt_variant == 7 || (ix->opt_variant == 0 && nq > 256)));
     constexpr int K3_KLL = 4; // entries per sub-list (the third accumulator set is paid for with shorter lists)
     // (a variant on 16-document stages -- 4-stage ring, three blocks in flight, one barrier per 16 documents -- was built and
     // measured 18 % SLOWER, 34.8 vs 29.5 ms at 2^22 x 1024: profiles/r3_pitch1024/README.md; what parks the waves is the barrier
@@ -260,6 +260,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
     // lists of 5 at depth 3, lists of 4 at depth 3; same results -- what a shorter list drops the margin check prices)
     if (want_v4 && ix->ld == 768 && (ix->opt_sub == 55 || ix->opt_sub == 56)) list_len = 5;
     if (want_v4 && ix->ld == 768 && ix->opt_sub == 57) list_len = 4;
+    if (want_k3 && ix->opt_sub >= 72 && ix->opt_sub <= 74) list_len = 3; // scan_kernel_k3 with sub-lists of 3: A prefetch depth 2 / 3 / 4
 #endif
     const size_t ncand = (size_t)nsplit * lists * list_len;
     int rc = ix->part_s.ensure((size_t)nq_pad * ncand * sizeof(float));
@@ -342,7 +343,25 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             else if (ix->opt_sub == 66) rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 6>);
             else if (ix->opt_sub == 67) rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 7>); // + L2 prefetch three blocks ahead
             else if (ix->opt_sub == 68) rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 8>); // ... six blocks ahead
-            else if (ix->opt_sub == 69) rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 9>); // ... three ahead, by one workgroup per document stream only
+            else if (ix->opt_sub == 72) rc3 = gok3(mips::scan_kernel_k3<3, 32, 2, 0, 1>);
+            else if (ix->opt_sub == 73) rc3 = gok3(mips::scan_kernel_k3<3, 32, 3, 0, 1>);
+            else if (ix->opt_sub == 74) rc3 = gok3(mips::scan_kernel_k3<3, 32, 4, 0, 1>);
+            else if (ix->opt_sub == 70) { // cycle accounting of the waves' waits (same results): printed to stderr, synchronises
+                static unsigned long long* dbg_dev = nullptr;
+                if (!dbg_dev) HIP_TRY(hipMalloc((void**)&dbg_dev, 64));
+                HIP_TRY(hipMemsetAsync(dbg_dev, 0, 64, st));
+                a.nq_dev = reinterpret_cast<const int*>(dbg_dev);
+                rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 10>);
+                a.nq_dev = ix->nq_dev;
+                unsigned long long h[8];
+                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(hipMemcpy(h, dbg_dev, 64, hipMemcpyDeviceToHost));
+                if (h[5] == 0) fprintf(stderr, "k3 waits: nothing recorded (rc %d)\n", rc3);
+                if (h[5] > 0)
+                    fprintf(stderr, "k3 waits per wave and block (shader cycles; %llu waves, %.1f blocks each): DMA wait %.0f  block barrier %.0f  pair %.0f  of %.0f per block\n",
+                            h[5], (double)h[4] / (double)h[5], (double)h[0] / (double)h[4], (double)h[1] / (double)h[4], (double)h[2] / (double)h[4],
+                            (double)h[3] / (double)h[4]);
+            } else if (ix->opt_sub == 69) rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 9>); // ... three ahead, by one workgroup per document stream only
             else
 #endif
             rc3 = gok3(mips::scan_kernel_k3<K3_KLL, 32, 2, 0, K3_PUB>);
@@ -399,6 +418,7 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             else if (ix->ld == 768 && ix->opt_sub == 46) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 6>); // timing only: no document DMA
             else if (ix->ld == 768 && ix->opt_sub == 47) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 7>); // timing only: no block barrier wait
             else if (ix->ld == 768 && ix->opt_sub == 48) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 8>); // timing only: no DMA, no epilogue
+            else if (ix->ld == 768 && ix->opt_sub == 58) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 14>); // DMA lane offset kept in a register
             else if (ix->ld == 768 && ix->opt_sub == 55) rc2 = go4(mips::scan_kernel_v4<5, 24, 2, 0>);
             else if (ix->ld == 768 && ix->opt_sub == 56) rc2 = go4(mips::scan_kernel_v4<5, 24, 3, 0>);
             else if (ix->ld == 768 && ix->opt_sub == 57) rc2 = go4(mips::scan_kernel_v4<4, 24, 3, 0>);

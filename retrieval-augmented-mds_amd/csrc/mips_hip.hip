@@ -457,7 +457,8 @@ static int search_impl(mips_index_t* ix, const void* q, int q_dtype, int64_t nq,
         // to the 8th best approximate one for one Gaussian query in ~3000 at 2^22 rows, and each flagged query costs a pass over the
         // index (3 ms there); the 16th best is out of reach.  Small indexes keep the pool of 8 (their exact pass is cheap).
         bool deep_1024 = !fast && k <= 5 && ix->plane == 0 && ix->esize == 2 && !ix->mixed && ix->ld == 1024 && nq > 256 && ix->ntotal >= (1ll << 21) &&
-                         ix->opt_margin != 0 && !split && (!out_dev || ix->opt_margin >= 2) && ix->opt_f32_fast != 0;
+                         ix->opt_margin != 0 && !split && (!out_dev || ix->opt_margin >= 2) && ix->opt_f32_fast != 0 && ix->opt_sub == 0 &&
+                         ix->opt_variant == 0; // (forced kernels and the A/B instances keep the pool of 8)
         if (deep_1024 && ix->fast_skip > 0) {
             --ix->fast_skip;
             deep_1024 = false;

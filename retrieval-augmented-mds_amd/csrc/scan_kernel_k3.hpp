@@ -60,6 +60,11 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
     const int split = (xcd / p.qgroups) * p.splits_per_group + j0 / p.qt_per_group;
     if (qt >= p.nqt) return;
     const bool pf_leader = (j0 % p.qt_per_group) == 0;
+    // TIMING_MODE 10 (diagnostic, same results): shader-clock cycles this wave spends in the DMA wait of its arrival, in the block
+    // barrier's poll and in the pair's poll, summed over the launch into the five words p.nq_dev points at (the launcher passes a
+    // scratch buffer there: tools/ab.py prints them)
+    unsigned long long t_vm = 0ull, t_bar = 0ull, t_pair = 0ull;
+    const unsigned long long t_start = TIMING_MODE == 10 ? __builtin_readcyclecounter() : 0ull;
     if (p.spin_limit < 0 && tid == 0) *p.err = 1u; // test-only: force the scan-error path (include/mips_hip.h, "spin_limit")
     const bool idle_pair = (qt * TN + pair * 16 * NCB) >= p.nq; // all 48 queries of the pair are padding (scan_kernel_v3.hpp)
 
@@ -158,8 +163,10 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
     auto arrive = [&](bool in_loop = true) {
         // 2-stage ring: this wave's share of the NEXT block has landed (the one younger operation that may still be in flight is
         // the block's L2 prefetch, issued after the pieces)
+        const unsigned long long t0 = TIMING_MODE == 10 ? __builtin_readcyclecounter() : 0ull;
         if (PREFETCH && in_loop) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (TIMING_MODE == 10) t_vm += __builtin_readcyclecounter() - t0;
         bump(cnt_lds);
     };
     // One dword of each 128-B line of a block PF_DIST blocks ahead, 64 lines per wave, into the dummy area: the L2 miss of that
@@ -286,7 +293,11 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
             }
         }
         // the partner's partial sums for MY half
-        if (TIMING_MODE != 3) poll(xcnt_partner, (unsigned)(blk - b0) + 1u);
+        {
+            const unsigned long long t0 = TIMING_MODE == 10 ? __builtin_readcyclecounter() : 0ull;
+            if (TIMING_MODE != 3) poll(xcnt_partner, (unsigned)(blk - b0) + 1u);
+            if (TIMING_MODE == 10) t_pair += __builtin_readcyclecounter() - t0;
+        }
         f32x4 own[NCB];
         {
             const unsigned char* slot = smem + XCH_AREA + (wave ^ 1) * XCH_WAVE + lane_id_here() * 16u;
@@ -333,7 +344,11 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
     if (nb > 0) arrive(false); // this wave's share of block 0 has landed
     for (int i = 0; i < nb; ++i) {
         arrivals_needed += WAVES;
-        poll(cnt_lds, arrivals_needed); // every share of block i landed; everyone is done with block i - 1
+        {
+            const unsigned long long t0 = TIMING_MODE == 10 ? __builtin_readcyclecounter() : 0ull;
+            poll(cnt_lds, arrivals_needed); // every share of block i landed; everyone is done with block i - 1
+            if (TIMING_MODE == 10) t_bar += __builtin_readcyclecounter() - t0;
+        }
         // (the last block of the range re-fetches ITSELF into the free stage instead of a next block: the pieces are issued
         // unconditionally, the MFMA chain stays one basic block)
         const unsigned char* nbase = first + (int64_t)(i + 1 < nb ? i + 1 : i) * blk_bytes;
@@ -341,6 +356,15 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_k3(ScanArgs p) {
         block(i < 8 || (i & 7) == 0, b0 + i, i & 1, nbase, (i + 1) & 1, first + (int64_t)ipf * blk_bytes);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (TIMING_MODE == 10 && p.nq_dev != nullptr && lane_id_here() == 0u && !idle_pair) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<int*>(p.nq_dev));
+        atomicAdd(dbg + 0, t_vm);
+        atomicAdd(dbg + 1, t_bar);
+        atomicAdd(dbg + 2, t_pair);
+        atomicAdd(dbg + 3, (unsigned long long)(__builtin_readcyclecounter() - t_start));
+        atomicAdd(dbg + 4, (unsigned long long)nb);
+        atomicAdd(dbg + 5, 1ull);
+    }
 
     // lists: [q][nsplit][8 = 2 document halves x 4 lane groups][KL]
 #pragma unroll

@@ -127,6 +127,16 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
     // ---- LDS-DMA map (as v3): piece pc = slab * 4 + rg, 8 rows x 128 B
     const unsigned char* docs_b = reinterpret_cast<const unsigned char*>(p.docs);
     const int64_t row_bytes = (int64_t)p.ld * 2;
+    // TIMING_MODE 14 (experiment, same results): the per-lane source offset lives in ONE register for the whole kernel instead of
+    // being re-derived from the lane id for every piece (~10 vector instructions each, 6 pieces per block and wave)
+    unsigned lane_off_kept = 0u;
+    if (TIMING_MODE == 14) {
+        const unsigned ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        lane_off_kept = (ln >> 3) * (unsigned)row_bytes + (((ln & 7u) ^ ((ln >> 4) & 7u)) << 4);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(lane_off_kept));
+#endif
+    }
     auto issue_piece = [&](const unsigned char* blk_base, int stage, int i) {
         if (TIMING_MODE == 6 || TIMING_MODE == 8) return; // diagnostic builds (results are wrong): the ring is never filled
         const __amdgpu_buffer_rsrc_t rsrc =
@@ -135,8 +145,11 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
         const int slab = pc >> 2, rg = pc & 3;
         // per-lane source offset, recomputed per piece from the lane id (the kernel has no VGPR to spare):
         // row lane >> 3 of the piece, chunk slot (lane & 7) ^ ((row >> 1) & 7) = (lane & 7) ^ ((4 rg + (lane >> 4)) & 7)
-        const unsigned ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        const unsigned lane_off0 = (ln >> 3) * (unsigned)row_bytes + (((ln & 7u) ^ ((ln >> 4) & 7u)) << 4);
+        unsigned lane_off0 = lane_off_kept;
+        if (TIMING_MODE != 14) {
+            const unsigned ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            lane_off0 = (ln >> 3) * (unsigned)row_bytes + (((ln & 7u) ^ ((ln >> 4) & 7u)) << 4);
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + stage * STAGE_BYTES + pc * 1024), 16,
                                                  (rg & 1) ? (lane_off0 ^ 64u) : lane_off0,
                                                  rg * 8 * (int)row_bytes + slab * 128, 0, NT_DOCS ? 2 : 0);
