@@ -418,7 +418,20 @@ int launch_search(mips_index* ix, int64_t nq, int k, float* d_out_s, int64_t* d_
             else if (ix->ld == 768 && ix->opt_sub == 46) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 6>); // timing only: no document DMA
             else if (ix->ld == 768 && ix->opt_sub == 47) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 7>); // timing only: no block barrier wait
             else if (ix->ld == 768 && ix->opt_sub == 48) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 8>); // timing only: no DMA, no epilogue
-            else if (ix->ld == 768 && ix->opt_sub == 58) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 14>); // DMA lane offset kept in a register
+            else if (ix->ld == 768 && ix->opt_sub == 59) { // cycle accounting of the waves' explicit waits (same results): stderr, synchronises
+                static unsigned long long* dbg_dev = nullptr;
+                if (!dbg_dev) HIP_TRY(hipMalloc((void**)&dbg_dev, 64));
+                HIP_TRY(hipMemsetAsync(dbg_dev, 0, 64, st));
+                a.nq_dev = reinterpret_cast<const int*>(dbg_dev);
+                rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 15>);
+                a.nq_dev = ix->nq_dev;
+                unsigned long long h[8];
+                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(hipMemcpy(h, dbg_dev, 64, hipMemcpyDeviceToHost));
+                if (h[5] > 0)
+                    fprintf(stderr, "v4 waits per wave and block (shader cycles; %llu waves, %.1f blocks each): DMA wait %.0f  block barrier %.0f  of %.0f per block\n",
+                            h[5], (double)h[4] / (double)h[5], (double)h[0] / (double)h[4], (double)h[1] / (double)h[4], (double)h[3] / (double)h[4]);
+            } else if (ix->ld == 768 && ix->opt_sub == 58) rc2 = go4(mips::scan_kernel_v4<V4_KLL, 24, 2, 14>); // DMA lane offset kept in a register
             else if (ix->ld == 768 && ix->opt_sub == 55) rc2 = go4(mips::scan_kernel_v4<5, 24, 2, 0>);
             else if (ix->ld == 768 && ix->opt_sub == 56) rc2 = go4(mips::scan_kernel_v4<5, 24, 3, 0>);
             else if (ix->ld == 768 && ix->opt_sub == 57) rc2 = go4(mips::scan_kernel_v4<4, 24, 3, 0>);

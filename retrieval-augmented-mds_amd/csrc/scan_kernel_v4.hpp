@@ -169,8 +169,16 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
     const unsigned cnt_lds = (unsigned)(size_t)(lds_void*)(smem + DUMP_AREA + 1024);
     unsigned arrivals_needed = 0;
     constexpr int PER_BLOCK = PPW + 1;
+    // TIMING_MODE 15 (diagnostic, same results): shader-clock cycles this wave spends in the DMA wait of its arrival and in the
+    // block barrier's poll, summed over the launch into the words p.nq_dev points at (the launcher passes a scratch buffer there)
+    // (32-bit sums of low words pinned to SGPRs: the kernel has no vector register for them)
+    auto clk = [&]() { return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)__builtin_readcyclecounter()); };
+    unsigned t_vm = 0u, t_bar = 0u;
+    const unsigned t_start = TIMING_MODE == 15 ? clk() : 0u;
     auto arrive = [&]() {
+        const unsigned t0 = TIMING_MODE == 15 ? clk() : 0u;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_BLOCK) : "memory");
+        if (TIMING_MODE == 15) t_vm += clk() - t0;
 #if defined(__HIP_DEVICE_COMPILE__)
         if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(cnt_lds), "v"(1u) : "memory");
 #endif
@@ -324,7 +332,11 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
     __syncthreads();
     if (nb > 0) arrive();
     for (int i = 0; i < nb; ++i) {
-        wait_all();
+        {
+            const unsigned t0 = TIMING_MODE == 15 ? clk() : 0u;
+            wait_all();
+            if (TIMING_MODE == 15) t_bar += clk() - t0;
+        }
         // TIMING_MODE 10 / 11 / 12 (experiment, same results): the second wave of each SIMD starts its block 64 / 128 / 192 cycles
         // late, so that the two waves' epilogues (an MFMA -> VALU dependency stall + ~10 dependent instructions per half, which both
         // reach at the same moment when they leave the barrier together) fall into each other's MFMA chains
@@ -335,6 +347,14 @@ __global__ __launch_bounds__(512, 2) void scan_kernel_v4(ScanArgs p) {
         pstage = pstage == STAGES - 1 ? 0 : pstage + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (TIMING_MODE == 15 && p.nq_dev != nullptr && lane_id_here() == 0u && !idle_wave) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<int*>(p.nq_dev));
+        atomicAdd(dbg + 0, (unsigned long long)t_vm);
+        atomicAdd(dbg + 1, (unsigned long long)t_bar);
+        atomicAdd(dbg + 3, (unsigned long long)(clk() - t_start));
+        atomicAdd(dbg + 4, (unsigned long long)nb);
+        atomicAdd(dbg + 5, 1ull);
+    }
 
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
